@@ -1,0 +1,19 @@
+#!/bin/bash
+# Builds libhipba.so (gfx950 only) in-tree; hipcc cross-compiles without a GPU.
+set -e
+cd "$(dirname "$0")"
+SRC=stereo_visual_odometry_amd/csrc
+OUT=stereo_visual_odometry_amd/lib
+mkdir -p "$OUT" build
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -munsafe-fp-atomics -Wall -Wno-unused-function -Iinclude"
+pids=()
+for f in lm_kernels dense_solver hipba_api; do
+  if [ ! -f build/$f.o ] || [ $SRC/$f.hip -nt build/$f.o ] || [ -n "$(find $SRC include -name '*.h*' -newer build/$f.o | head -1)" ]; then
+    $HIPCC $FLAGS -c $SRC/$f.hip -o build/$f.o &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait $p; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT/libhipba.so build/lm_kernels.o build/dense_solver.o build/hipba_api.o
+echo "built $OUT/libhipba.so"

@@ -1,0 +1,251 @@
+/*
+ * hipba.h -- C ABI of the MI355X (gfx950) bundle-adjustment engine.
+ *
+ * This is the boundary a maintainer of the reference binds to in place of the
+ * ceres::Problem / ceres::Solve calls inside VO::Optimizer::optimize
+ * (reference: src/solve/optimizer.cpp:14-63).  Plain pointers and sizes only.
+ *
+ * Conventions shared by every entry point
+ *   - poses are 7 doubles each, qx qy qz qw tx ty tz, exactly the memory of
+ *     Sophus::SE3d::data() (reference: include/visual_odometry/sensor/frame.hpp:28,
+ *     src/solve/optimizer.cpp:27); the pose is T_world<-camera.
+ *   - landmarks are 3 doubles each (reference: sensor/map_point.hpp:20,
+ *     src/solve/optimizer.cpp:21).
+ *   - an observation is (pose index, landmark index, u, v) -- one
+ *     AddResidualBlock of src/solve/optimizer.cpp:47-50; pixels are doubles as at
+ *     optimizer.cpp:40-41.
+ *   - every function returns HIPBA_OK (0) or a negative HIPBA_ERR_* code and
+ *     never throws; hipba_last_error() gives the text for the calling thread.
+ *   - caller memory is never retained past the call that received it.
+ *   - results are written back only when the solution is usable, as Ceres does
+ *     (termination CONVERGENCE or NO_CONVERGENCE); otherwise inputs stay untouched.
+ */
+#ifndef HIPBA_H_
+#define HIPBA_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HIPBA_VERSION 100
+
+/* status codes */
+enum {
+  HIPBA_OK = 0,
+  HIPBA_ERR_INVALID_ARGUMENT = -1,
+  HIPBA_ERR_NO_DEVICE = -2,        /* no usable gfx950 device: there is no CPU fallback */
+  HIPBA_ERR_HIP = -3,              /* a HIP runtime call failed */
+  HIPBA_ERR_OUT_OF_MEMORY = -4,
+  HIPBA_ERR_UNSUPPORTED = -5,      /* e.g. a landmark with more than HIPBA_MAX_POINT_DEGREE observations */
+  HIPBA_ERR_COMM = -6              /* the caller's all-reduce callback failed */
+};
+
+/* reference: optimizer.hpp:56-57 (z forward, production) vs test/ba_test.h:205-206 (x forward) */
+enum { HIPBA_CAMERA_Z_FORWARD = 0, HIPBA_CAMERA_X_FORWARD = 1 };
+/* reference: optimizer.cpp:48 passes no loss; test/ba_test.cpp:241 uses ceres::HuberLoss(scale) */
+enum { HIPBA_LOSS_NONE = 0, HIPBA_LOSS_HUBER = 1 };
+/* how the reduced camera system is solved */
+enum { HIPBA_LINEAR_AUTO = 0, HIPBA_LINEAR_DENSE_CHOLESKY = 1, HIPBA_LINEAR_PCG = 2 };
+/* ceres::TerminationType */
+enum { HIPBA_CONVERGENCE = 0, HIPBA_NO_CONVERGENCE = 1, HIPBA_FAILURE = 2 };
+
+#define HIPBA_MAX_POINT_DEGREE 256
+
+/*
+ * One window: what VO::Optimizer::optimize walks out of VO::Map
+ * (reference: optimizer.cpp:19-52; sensor/map.hpp:21-22).
+ */
+typedef struct hipba_problem {
+  int32_t n_poses;
+  double* poses;              /* [7*n_poses] in/out */
+  const uint8_t* pose_const;  /* [n_poses] or NULL; 1 = SetParameterBlockConstant (optimizer.cpp:30) */
+  int32_t n_points;
+  double* points;             /* [3*n_points] in/out */
+  const uint8_t* point_const; /* [n_points] or NULL (optimizer.cpp:33) */
+  int64_t n_obs;
+  const int32_t* obs_pose;    /* [n_obs] */
+  const int32_t* obs_point;   /* [n_obs] */
+  const double* obs_uv;       /* [2*n_obs] */
+  double fx, fy, cx, cy;      /* K(0,0) K(1,1) K(0,2) K(1,2) (sensor/camera.hpp:16) */
+  int32_t camera_model;       /* HIPBA_CAMERA_* */
+} hipba_problem;
+
+/*
+ * ceres::Solver::Options fields the reference relies on, same names, Ceres'
+ * defaults (reference: optimizer.cpp:54-58 overrides max_num_iterations = 300;
+ * test/ba_test.cpp:269-271 keeps 50).
+ */
+typedef struct hipba_options {
+  int32_t max_num_iterations;               /* 50 */
+  int32_t loss;                             /* HIPBA_LOSS_NONE */
+  double loss_scale;                        /* 1.0 */
+  int32_t linear_solver;                    /* HIPBA_LINEAR_AUTO */
+  int32_t jacobi_scaling;                   /* 1 */
+  double initial_trust_region_radius;       /* 1e4 */
+  double max_trust_region_radius;           /* 1e16 */
+  double min_trust_region_radius;           /* 1e-32 */
+  double min_relative_decrease;             /* 1e-3 */
+  double min_lm_diagonal;                   /* 1e-6 */
+  double max_lm_diagonal;                   /* 1e32 */
+  int32_t max_num_consecutive_invalid_steps;/* 5 */
+  double function_tolerance;                /* 1e-6 */
+  double gradient_tolerance;                /* 1e-10 */
+  double parameter_tolerance;               /* 1e-8 */
+  int32_t pcg_max_iterations;               /* 500 */
+  double pcg_tolerance;                     /* 1e-12, relative residual |r|/|b| */
+  int32_t minimizer_progress_to_stdout;     /* 0; 1 prints a Ceres-like table (optimizer.cpp:56) */
+  int32_t reserved;
+} hipba_options;
+
+/* ceres::IterationSummary, the fields the reference prints */
+typedef struct hipba_iteration {
+  int32_t iteration;
+  int32_t step_is_valid;
+  int32_t step_is_successful;
+  int32_t linear_solver_iterations;
+  double cost;
+  double cost_change;
+  double gradient_max_norm;
+  double gradient_norm;
+  double step_norm;
+  double relative_decrease;
+  double trust_region_radius;
+} hipba_iteration;
+
+/* ceres::Solver::Summary, reduced to what is measurable here */
+typedef struct hipba_summary {
+  int32_t termination_type;        /* HIPBA_CONVERGENCE ... */
+  int32_t num_iterations;          /* entries in the iteration log, iteration 0 included */
+  int32_t num_successful_steps;
+  int32_t num_unsuccessful_steps;
+  double initial_cost;
+  double final_cost;
+  double fixed_cost;
+  int32_t num_active_poses;
+  int32_t num_active_points;
+  int64_t num_active_observations;
+  double time_setup_s;             /* host analysis + upload */
+  double time_solve_s;             /* LM loop on the device */
+  double time_total_s;
+  int32_t linear_solver_used;      /* HIPBA_LINEAR_DENSE_CHOLESKY or HIPBA_LINEAR_PCG */
+  int32_t reserved;
+  /* optional per-iteration log: caller-provided storage for iteration_log_capacity entries */
+  hipba_iteration* iteration_log;
+  int32_t iteration_log_capacity;
+  int32_t reserved2;
+} hipba_summary;
+
+typedef struct hipba_handle_s* hipba_handle;          /* one per calling thread and GPU */
+typedef struct hipba_device_problem_s* hipba_device_problem;
+
+/*
+ * All-reduce over the ranks of a job, supplied by the caller (RCCL through
+ * torch.distributed, or a wrapper around a raw ncclComm_t).  buf is DEVICE memory
+ * holding count doubles; op is HIPBA_REDUCE_SUM or HIPBA_REDUCE_MAX; stream is the
+ * hipStream_t the engine works on (the callee must order its collective after
+ * work already queued on it, and leave the result visible to later work on it).
+ * Return 0 on success.
+ */
+enum { HIPBA_REDUCE_SUM = 0, HIPBA_REDUCE_MAX = 1 };
+typedef int (*hipba_allreduce_fn)(void* ctx, double* buf, size_t count, int op, void* stream);
+
+typedef struct hipba_comm {
+  hipba_allreduce_fn allreduce;
+  void* ctx;
+  int32_t rank;
+  int32_t world_size;
+} hipba_comm;
+
+/* ---- library ---------------------------------------------------------------------------- */
+int hipba_version(void);
+const char* hipba_last_error(void);
+void hipba_options_default(hipba_options* options);
+
+/* ---- handle: owns the device, one stream and grow-only device buffers ------------------- */
+int hipba_create(int device, hipba_handle* out);
+int hipba_destroy(hipba_handle h);
+/* hipStream_t of the handle, for callers that order their own work (or a collective) on it */
+void* hipba_stream(hipba_handle h);
+
+/*
+ * Replaces ceres::Solve on one window (reference: optimizer.cpp:61): analyses the
+ * problem on the host, uploads it, runs Levenberg-Marquardt on the GPU, writes
+ * poses/points back in place when the solution is usable.
+ */
+int hipba_solve(hipba_handle h, hipba_problem* problem, const hipba_options* options,
+                hipba_summary* summary);
+
+/*
+ * Many independent windows in one call (small sliding windows batched on one
+ * GPU).  Each window keeps its own trust region, acceptance test and
+ * termination; summaries[i] belongs to problems[i].
+ */
+int hipba_solve_batched(hipba_handle h, int32_t n_windows, hipba_problem* problems,
+                        const hipba_options* options, hipba_summary* summaries);
+
+/*
+ * ceres::Problem::Evaluate for the same residual blocks: residuals [2*n_obs],
+ * jac_pose [12*n_obs] (2x6 row-major in the SE3 tangent space v0 v1 v2 w0 w1 w2,
+ * i.e. ambient Jacobian x Sophus::Manifold<SE3>::PlusJacobian), jac_point
+ * [6*n_obs] (2x3 row-major).  Any output may be NULL.  With apply_loss != 0 the
+ * robust-loss corrector is applied as Ceres' ResidualBlock::Evaluate does and
+ * *cost = 1/2 sum rho(|r|^2); otherwise *cost = 1/2 sum |r|^2.  Constant flags
+ * are ignored (every block is differentiated).
+ */
+int hipba_evaluate(hipba_handle h, const hipba_problem* problem, const hipba_options* options,
+                   int apply_loss, double* cost, double* residuals, double* jac_pose,
+                   double* jac_point);
+
+/* ---- device-resident problems: upload once, solve/reset many times ---------------------- */
+int hipba_upload(hipba_handle h, int32_t n_windows, const hipba_problem* problems,
+                 hipba_device_problem* out);
+/*
+ * Upload ONE window's shard for hipba_solve_device_sharded: all poses of the window (identical on
+ * every rank) and this rank's landmarks with all of their observations.  Unlike hipba_upload every
+ * non-constant pose takes part in the reduced system even if this rank holds none of its
+ * observations, so that all ranks lay the reduced camera matrix out identically.
+ */
+int hipba_upload_shard(hipba_handle h, const hipba_problem* shard, hipba_device_problem* out);
+/* restore the parameters uploaded by hipba_upload (device-to-device copy) */
+int hipba_reset(hipba_handle h, hipba_device_problem dp);
+/* LM on the resident problem; summaries [n_windows] */
+int hipba_solve_device(hipba_handle h, hipba_device_problem dp, const hipba_options* options,
+                       hipba_summary* summaries);
+/*
+ * As hipba_solve_device for ONE window whose observations are a shard of a larger
+ * problem: every rank holds all poses and a disjoint subset of the landmarks with
+ * all of their observations.  The reduced camera matrix, its right-hand side and
+ * the per-iteration scalars are summed over ranks through comm.
+ */
+int hipba_solve_device_sharded(hipba_handle h, hipba_device_problem dp, const hipba_comm* comm,
+                               const hipba_options* options, hipba_summary* summary);
+/* copy current device parameters of window w back: poses [7*n_poses], points [3*n_points] */
+int hipba_download(hipba_handle h, hipba_device_problem dp, int32_t window, double* poses,
+                   double* points);
+int hipba_free_problem(hipba_handle h, hipba_device_problem dp);
+
+/* ---- measurement hooks (bench / profiling; no counterpart in the reference) ------------- */
+enum {
+  HIPBA_KERNEL_RESIDUAL = 0,          /* cost pass                                  */
+  HIPBA_KERNEL_RESIDUAL_JACOBIAN = 1, /* one thread per observation, r + J to HBM   */
+  HIPBA_KERNEL_CAMERA_BLOCKS = 2,     /* 6x6 camera blocks + gradient               */
+  HIPBA_KERNEL_POINT_SCHUR = 3,       /* 3x3 inversion + Schur complement           */
+  HIPBA_KERNEL_BACKSUB = 4,           /* landmark back-substitution + model change  */
+  HIPBA_KERNEL_REDUCED_SOLVE = 5,     /* Cholesky / PCG on the reduced system       */
+  HIPBA_KERNEL_COUNT = 6
+};
+/*
+ * Launches one hot-path kernel `repeats` times on the resident problem's current
+ * state and returns the average duration of one launch in milliseconds measured
+ * with HIP events on the handle's stream.  Does not change the parameters.
+ */
+int hipba_time_kernel(hipba_handle h, hipba_device_problem dp, const hipba_options* options,
+                      int32_t kernel, int32_t repeats, double* avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIPBA_H_ */

@@ -1,0 +1,233 @@
+"""ctypes access to the CPU oracle (oracle/libba_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py -- never by the product package.  PARITY UNPINNED:
+see the header of ba_oracle.h.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libba_oracle.so")
+
+Z_FORWARD, X_FORWARD = 0, 1
+LOSS_NONE, LOSS_HUBER = 0, 1
+JAC_NUMERIC, JAC_ANALYTIC = 0, 1
+LIN_AUTO, LIN_FULL, LIN_SCHUR = 0, 1, 2
+CONVERGENCE, NO_CONVERGENCE, FAILURE = 0, 1, 2
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_bp = C.POINTER(C.c_uint8)
+
+
+class CProblem(C.Structure):
+    _fields_ = [
+        ("n_poses", C.c_int32), ("poses", _dp), ("pose_const", _bp),
+        ("n_points", C.c_int32), ("points", _dp), ("point_const", _bp),
+        ("n_obs", C.c_int64), ("obs_pose", _ip), ("obs_point", _ip), ("obs_uv", _dp),
+        ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+        ("camera_model", C.c_int32),
+    ]
+
+
+class COptions(C.Structure):
+    _fields_ = [
+        ("max_num_iterations", C.c_int32), ("loss", C.c_int32), ("loss_scale", C.c_double),
+        ("jacobian_mode", C.c_int32), ("linear_solver", C.c_int32), ("num_threads", C.c_int32),
+        ("jacobi_scaling", C.c_int32), ("param_tol_needs_success", C.c_int32),
+        ("initial_trust_region_radius", C.c_double), ("max_trust_region_radius", C.c_double),
+        ("min_trust_region_radius", C.c_double), ("min_relative_decrease", C.c_double),
+        ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
+        ("max_num_consecutive_invalid_steps", C.c_int32),
+        ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double),
+        ("parameter_tolerance", C.c_double),
+    ]
+
+
+class CIteration(C.Structure):
+    _fields_ = [
+        ("iteration", C.c_int32), ("step_is_valid", C.c_int32), ("step_is_successful", C.c_int32),
+        ("cost", C.c_double), ("cost_change", C.c_double), ("gradient_max_norm", C.c_double),
+        ("gradient_norm", C.c_double), ("step_norm", C.c_double), ("relative_decrease", C.c_double),
+        ("trust_region_radius", C.c_double),
+    ]
+
+
+class CSummary(C.Structure):
+    _fields_ = [
+        ("termination_type", C.c_int32), ("num_iterations", C.c_int32),
+        ("num_successful_steps", C.c_int32), ("num_unsuccessful_steps", C.c_int32),
+        ("initial_cost", C.c_double), ("final_cost", C.c_double), ("fixed_cost", C.c_double),
+        ("time_evaluate_s", C.c_double), ("time_linear_solve_s", C.c_double), ("time_total_s", C.c_double),
+        ("num_active_poses", C.c_int32), ("num_active_points", C.c_int32), ("num_active_obs", C.c_int64),
+    ]
+
+
+_lib = None
+
+
+def build():
+    """Compile the oracle with gcc (seconds)."""
+    subprocess.check_call(["make", "-C", _HERE, "-s"])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.oracle_options_default.argtypes = [C.POINTER(COptions)]
+        _lib.oracle_residual.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
+                                         _dp, _dp, C.c_double, C.c_double, _dp]
+        _lib.oracle_se3_exp.argtypes = [_dp, _dp]
+        _lib.oracle_se3_mul.argtypes = [_dp, _dp, _dp]
+        _lib.oracle_se3_plus.argtypes = [_dp, _dp, _dp]
+        _lib.oracle_se3_inverse.argtypes = [_dp, _dp]
+        _lib.oracle_se3_plus_jacobian.argtypes = [_dp, _dp]
+        _lib.oracle_evaluate.argtypes = [C.POINTER(CProblem), C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,
+                                         _dp, _dp, _dp, _dp, _dp]
+        _lib.oracle_evaluate.restype = C.c_int
+        _lib.oracle_solve.argtypes = [C.POINTER(CProblem), C.POINTER(COptions), C.POINTER(CSummary),
+                                      C.POINTER(CIteration)]
+        _lib.oracle_solve.restype = C.c_int
+        _lib.oracle_lm_step.argtypes = [C.POINTER(CProblem), C.POINTER(COptions), C.c_double, _dp, _dp, _dp]
+        _lib.oracle_lm_step.restype = C.c_int
+    return _lib
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+class Problem:
+    """Flat BA problem (copies its inputs; poses/points are updated in place by solve)."""
+
+    def __init__(self, poses, points, obs_pose, obs_point, obs_uv, K, camera_model=Z_FORWARD,
+                 pose_const=None, point_const=None):
+        self.poses = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 7).copy()
+        self.points = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3).copy()
+        self.obs_pose = np.ascontiguousarray(obs_pose, dtype=np.int32).copy()
+        self.obs_point = np.ascontiguousarray(obs_point, dtype=np.int32).copy()
+        self.obs_uv = np.ascontiguousarray(obs_uv, dtype=np.float64).reshape(-1, 2).copy()
+        self.K = tuple(float(k) for k in K)  # fx fy cx cy
+        self.camera_model = int(camera_model)
+        self.pose_const = None if pose_const is None else np.ascontiguousarray(pose_const, dtype=np.uint8).copy()
+        self.point_const = None if point_const is None else np.ascontiguousarray(point_const, dtype=np.uint8).copy()
+
+    def c(self):
+        p = CProblem()
+        p.n_poses = self.poses.shape[0]
+        p.poses = _d(self.poses)
+        p.pose_const = None if self.pose_const is None else self.pose_const.ctypes.data_as(_bp)
+        p.n_points = self.points.shape[0]
+        p.points = _d(self.points)
+        p.point_const = None if self.point_const is None else self.point_const.ctypes.data_as(_bp)
+        p.n_obs = self.obs_pose.shape[0]
+        p.obs_pose = self.obs_pose.ctypes.data_as(_ip)
+        p.obs_point = self.obs_point.ctypes.data_as(_ip)
+        p.obs_uv = _d(self.obs_uv)
+        p.fx, p.fy, p.cx, p.cy = self.K
+        p.camera_model = self.camera_model
+        return p
+
+
+def default_options(**kw):
+    o = COptions()
+    lib().oracle_options_default(C.byref(o))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise AttributeError(k)
+        setattr(o, k, v)
+    return o
+
+
+def residual(camera_model, K, pose7, point3, u, v):
+    pose7 = np.ascontiguousarray(pose7, dtype=np.float64)
+    point3 = np.ascontiguousarray(point3, dtype=np.float64)
+    out = np.zeros(2)
+    lib().oracle_residual(camera_model, K[0], K[1], K[2], K[3], _d(pose7), _d(point3), float(u), float(v), _d(out))
+    return out
+
+
+def se3_exp(t6):
+    t6 = np.ascontiguousarray(t6, dtype=np.float64)
+    out = np.zeros(7)
+    lib().oracle_se3_exp(_d(t6), _d(out))
+    return out
+
+
+def se3_mul(a, b):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    out = np.zeros(7)
+    lib().oracle_se3_mul(_d(a), _d(b), _d(out))
+    return out
+
+
+def se3_plus(pose7, d6):
+    pose7 = np.ascontiguousarray(pose7, dtype=np.float64)
+    d6 = np.ascontiguousarray(d6, dtype=np.float64)
+    out = np.zeros(7)
+    lib().oracle_se3_plus(_d(pose7), _d(d6), _d(out))
+    return out
+
+
+def se3_inverse(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    out = np.zeros(7)
+    lib().oracle_se3_inverse(_d(a), _d(out))
+    return out
+
+
+def se3_plus_jacobian(pose7):
+    pose7 = np.ascontiguousarray(pose7, dtype=np.float64)
+    out = np.zeros((7, 6))
+    lib().oracle_se3_plus_jacobian(_d(pose7), _d(out))
+    return out
+
+
+def evaluate(prob, jacobian_mode=JAC_ANALYTIC, loss=LOSS_NONE, loss_scale=1.0, apply_loss=True,
+             num_threads=1, ambient=False):
+    """Returns dict(cost, residuals[N,2], jac_pose[N,2,6], jac_point[N,2,3], (jac_pose_ambient[N,2,7]))."""
+    n = prob.obs_pose.shape[0]
+    res = np.zeros((n, 2))
+    jc = np.zeros((n, 2, 6))
+    jp = np.zeros((n, 2, 3))
+    ja = np.zeros((n, 2, 7)) if ambient else None
+    cost = C.c_double(0.0)
+    cp = prob.c()
+    rc = lib().oracle_evaluate(C.byref(cp), jacobian_mode, loss, float(loss_scale), int(bool(apply_loss)),
+                               num_threads, C.cast(C.byref(cost), _dp), _d(res), _d(jc), _d(jp),
+                               _d(ja) if ambient else None)
+    out = {"rc": rc, "cost": cost.value, "residuals": res, "jac_pose": jc, "jac_point": jp}
+    if ambient:
+        out["jac_pose_ambient"] = ja
+    return out
+
+
+def solve(prob, options=None):
+    """Runs the restated Ceres solve in place on prob; returns (summary dict, iteration list)."""
+    o = options if options is not None else default_options()
+    s = CSummary()
+    log = (CIteration * (o.max_num_iterations + 2))()
+    cp = prob.c()
+    rc = lib().oracle_solve(C.byref(cp), C.byref(o), C.byref(s), log)
+    summ = {f[0]: getattr(s, f[0]) for f in CSummary._fields_}
+    summ["rc"] = rc
+    its = [{f[0]: getattr(log[i], f[0]) for f in CIteration._fields_} for i in range(s.num_iterations)]
+    return summ, its
+
+
+def lm_step(prob, options, radius):
+    sp = np.zeros((prob.poses.shape[0], 6))
+    sq = np.zeros((prob.points.shape[0], 3))
+    mc = C.c_double(0.0)
+    cp = prob.c()
+    rc = lib().oracle_lm_step(C.byref(cp), C.byref(options), float(radius), _d(sp), _d(sq),
+                              C.cast(C.byref(mc), _dp))
+    return rc, sp, sq, mc.value

@@ -1,0 +1,137 @@
+// ba_device.hpp -- device-side data layout of a resident bundle-adjustment problem.
+//
+// One resident problem holds n_windows independent windows (one for hipba_solve, many
+// for hipba_solve_batched).  Everything a kernel needs travels in a DevP passed by
+// value; the per-window Levenberg-Marquardt state lives in device memory (WinState) so
+// that acceptance, trust-region update and termination run on the GPU.
+//
+// Observation classes, by which of the two parameter blocks is variable
+// (reference: SetParameterBlockConstant at src/solve/optimizer.cpp:30,33):
+//   PM section  variable landmark (pose variable or constant), sorted by
+//               (window, landmark, pose): a landmark's observations are one contiguous
+//               segment, and segments never straddle a 256-observation block.
+//   VC section  variable pose, constant landmark.
+//   CC section  both constant: evaluated once, Ceres' "fixed cost".
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/hipba.h"
+#include "ba_math.hpp"
+
+namespace hipba {
+
+constexpr int kBlock = 256;        // threads per workgroup in the observation kernels
+constexpr int kPartialStride = 4;  // doubles of per-block partial results
+constexpr int kSmallMaxN = 192;    // largest reduced system solved inside one workgroup's LDS
+
+// modes of the per-window kernels (see lm_kernels.hip)
+enum { kFused = 0, kReduce = 1, kDecide = 2 };
+
+struct BlockDesc {
+  long long obs_begin;   // first observation (index into obs_* arrays)
+  long long pair_begin;  // first entry of this block's pair list
+  int n_obs;             // <= kBlock
+  int n_pairs;
+  int window;
+  int kind;              // 0 = PM, 1 = VC, 2 = CC
+};
+
+struct WinDesc {
+  CameraK K;
+  int pose_begin, pose_end;    // device pose range of this window
+  int cam_base, ncam;          // first global slot and number of variable observed poses
+  long long S_off;             // offset (doubles) of this window's packed reduced matrix
+  int pm_blk_begin, pm_blk_end;
+  int vc_blk_begin, vc_blk_end;
+  int cc_blk_begin, cc_blk_end;
+  int pp_begin, pp_end;        // variable observed landmarks of this window
+  int log_base;                // first entry of this window in the iteration log
+  int pad;
+};
+
+struct WinState {
+  int sel;              // which parameter buffer holds x
+  int active;           // still iterating
+  int termination;      // HIPBA_CONVERGENCE / NO_CONVERGENCE / FAILURE
+  int iteration;        // index of the last logged iteration
+  int n_invalid;        // consecutive invalid steps
+  int any_success;
+  int num_successful;
+  int num_unsuccessful;
+  int solve_failed;     // set by the reduced solver of the current iteration
+  int last_success_log; // log entry whose gradient norms are filled by the next linearisation
+  int lin_iters;
+  int pad;
+  double radius;
+  double decrease_factor;
+  double x_cost;
+  double initial_cost;
+  double fixed_cost;
+  double gmax, gnorm;
+  // scratch written by per-window kernels of the current iteration
+  double pose_step2, pose_x2, pose_gmax, pose_g2;
+};
+
+struct LmParams {
+  int max_num_iterations;
+  int loss;
+  double loss_scale;
+  int jacobi_scaling;
+  int max_invalid;
+  double max_radius, min_radius, min_relative_decrease;
+  double min_lm_diagonal, max_lm_diagonal;
+  double function_tolerance, gradient_tolerance, parameter_tolerance;
+  double initial_radius;
+};
+
+struct DevP {
+  int n_poses, n_points, n_windows;
+  int n_act_poses;     // global slots
+  int n_pm_points;
+  long long n_pm_obs, n_act_obs, n_all_obs;
+  int n_blk_pm, n_blk_vc, n_blk_cc;  // blocks are stored PM | VC | CC
+  // parameters, double buffered (x and candidate); constant / unobserved blocks identical in both
+  double* poses[2];
+  double* points[2];
+  // per pose
+  const int* pose_window;
+  const int* pose_gslot;   // global slot or -1
+  // per global slot
+  const int* slot_pose;
+  const long long* cm_start;  // [n_act_poses+1] camera-major observation lists
+  const int* cm_dp;
+  const double* cm_uv;        // [2*]
+  // observations (PM | VC | CC)
+  const int* obs_pose;
+  const int* obs_dp;
+  const double* obs_uv;       // [2*]
+  const long long* pp_obs_start;  // [n_pm_points+1]
+  const BlockDesc* blocks;
+  const unsigned short* pairs;    // low byte = lane i, high byte = lane j, slot_i <= slot_j
+  const WinDesc* wd;
+  WinState* ws;
+  // work arrays
+  double* U;        // [36*n_act_poses] scaled camera blocks
+  double* gc;       // [6*n_act_poses]  scaled camera gradient
+  double* scale_c;  // [6*n_act_poses]
+  double* b;        // [6*n_act_poses]  reduced right-hand side
+  double* yc;       // [6*n_act_poses]  reduced solution
+  double* Vinv;     // [6*n_pm_points]  (V + D^2)^-1, symmetric packing
+  double* gp;       // [3*n_pm_points]  scaled landmark gradient
+  double* scale_p;  // [3*n_pm_points]
+  double* S;        // packed upper block-triangular reduced matrices, 36 doubles per 6x6 block
+  double* partial;  // [2 banks][kPartialStride * n_blocks]
+  double* gpart;    // [2 * n_blk_pm] landmark gradient max / sum of squares per PM block
+  double* wsum;     // [8 * n_windows] per-window sums handed to the all-reduce of sharded solves
+  int sharded;      // 1 when this rank holds only a shard of the window's landmarks
+  hipba_iteration* log;
+  int log_cap;      // entries per window
+};
+
+// packed upper block-triangular index of block (r, c), r <= c, for n block rows
+__host__ __device__ __forceinline__ long long tri_index(int r, int c, int n) {
+  return (long long)r * n - ((long long)r * (r - 1)) / 2 + (c - r);
+}
+
+}  // namespace hipba

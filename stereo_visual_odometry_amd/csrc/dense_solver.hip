@@ -1,0 +1,568 @@
+// dense_solver.hip -- reduced camera system of ONE large window (6*ncam > 192 unknowns).
+//
+// The reference hands the whole damped normal-equation system to Ceres'
+// SPARSE_NORMAL_CHOLESKY (src/solve/optimizer.cpp:55).  Here the landmarks have already
+// been eliminated (lm_kernels.hip), leaving S y = b with S dense-ish and symmetric
+// positive definite.  Two solvers:
+//   * blocked right-looking Cholesky, fp64, trailing update and panel solve on the
+//     matrix cores (v_mfma_f64_16x16x4_f64) -- exact, used when the camera count makes S a
+//     true dense contraction;
+//   * block-Jacobi preconditioned conjugate gradients straight on the packed block storage.
+//
+// Storage: P.S holds the upper block triangle, 6x6 blocks of 36 contiguous doubles.
+// The factorisation works on a column-major lower-triangular copy A (leading dimension
+// npad, a multiple of the 128-wide panel), padded with an identity block.
+#include <hip/hip_runtime.h>
+
+#include "hipba_internal.hpp"
+
+namespace hipba {
+
+constexpr int NB = kCholNB;  // 128
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+// ---- workspace -----------------------------------------------------------------------------------
+static size_t rup(size_t v, size_t a) { return (v + a - 1) / a * a; }
+constexpr int kPcgScalars = 16;
+
+size_t big_work_bytes(int n, int ncam) {
+  const size_t npad = rup((size_t)n, NB);
+  size_t b = 0;
+  b += rup(npad * npad * 8, 256);            // A
+  b += rup((npad / NB) * NB * NB * 8, 256);  // Linv
+  b += rup(2 * npad * 8, 256);               // rhs, z
+  b += rup((6 * npad + kPcgScalars + 3 * (size_t)ncam + 64) * 8, 256);  // pcg vectors + scalars + partials
+  b += rup((size_t)36 * ncam * 8, 256);      // Minv
+  return b + 1024;
+}
+
+void big_work_bind(BigWork& W, int n, int ncam, void* base) {
+  const size_t npad = rup((size_t)n, NB);
+  char* p = static_cast<char*>(base);
+  W.n = n; W.npad = (int)npad;
+  W.A = reinterpret_cast<double*>(p); p += rup(npad * npad * 8, 256);
+  W.Linv = reinterpret_cast<double*>(p); p += rup((npad / NB) * NB * NB * 8, 256);
+  W.rhs = reinterpret_cast<double*>(p); p += rup(2 * npad * 8, 256);
+  W.pcg = reinterpret_cast<double*>(p); p += rup((6 * npad + kPcgScalars + 3 * (size_t)ncam + 64) * 8, 256);
+  W.Minv = reinterpret_cast<double*>(p);
+}
+
+// ---- packed blocks -> dense column-major lower ----------------------------------------------------
+__global__ void k_unpack_lower(DevP P, double* A, int ld) {
+  if (!P.ws[0].active) return;
+  const int ncam = P.wd[0].ncam;
+  const int bi = blockIdx.y;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nb = ncam - bi;
+  if (e >= nb * 36) return;
+  const int bj = bi + e / 36, ac = e % 36, a = ac / 6, c = ac % 6;
+  const double v = P.S[P.wd[0].S_off + 36ll * tri_index(bi, bi, ncam) + e];
+  const int row = 6 * bj + c, col = 6 * bi + a;
+  if (row >= col) A[(long long)col * ld + row] = v;
+}
+
+__global__ void k_pad_init(DevP P, double* A, double* rhs, int n, int ld) {
+  if (!P.ws[0].active) return;
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= ld) return;
+  for (int row = n; row < ld; ++row) A[(long long)col * ld + row] = (row == col) ? 1.0 : 0.0;
+  rhs[col] = col < n ? P.b[6ll * P.wd[0].cam_base + col] : 0.0;
+}
+
+// ---- diagonal block: Cholesky in LDS + explicit inverse of the factor --------------------------
+__device__ __forceinline__ int lidx(int i, int k) { return i * (i + 1) / 2 + k; }
+
+__global__ __launch_bounds__(256) void k_potrf_inv(DevP P, double* A, int ld, int k, double* Linv_all) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  if (!P.ws[0].active || P.ws[0].solve_failed) return;
+  double* L = smem;                      // packed lower, NB*(NB+1)/2
+  double* X = smem + NB * (NB + 1) / 2;  // packed lower inverse
+  int& fail = *reinterpret_cast<int*>(X + NB * (NB + 1) / 2);
+  const int t = threadIdx.x;
+  double* Akk = A + (long long)k * NB * ld + k * NB;
+  for (int e = t; e < NB * NB; e += 256) {
+    const int c = e / NB, r = e % NB;
+    if (r >= c) L[lidx(r, c)] = Akk[(long long)c * ld + r];
+  }
+  if (t == 0) fail = 0;
+  __syncthreads();
+  const int ti = t & 15, tk = t >> 4;
+  for (int j = 0; j < NB; ++j) {
+    const double d = L[lidx(j, j)];
+    if (!(d > 0.0) || !isfinite(d)) {
+      if (t == 0) fail = 1;
+      break;
+    }
+    const double inv = 1.0 / sqrt(d);
+    __syncthreads();
+    for (int i = j + t; i < NB; i += 256) L[lidx(i, j)] *= inv;
+    __syncthreads();
+    for (int i = j + 1 + ti; i < NB; i += 16) {
+      const double lij = L[lidx(i, j)];
+      for (int c = j + 1 + tk; c <= i; c += 16) L[lidx(i, c)] -= lij * L[lidx(c, j)];
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  if (fail) {
+    if (t == 0) P.ws[0].solve_failed = 1;
+    return;
+  }
+  for (int e = t; e < NB * NB; e += 256) {
+    const int c = e / NB, r = e % NB;
+    if (r >= c) Akk[(long long)c * ld + r] = L[lidx(r, c)];
+  }
+  // X = L^-1, thread j owns column j (forward substitution down the column)
+  if (t < NB) {
+    const int j = t;
+    for (int i = 0; i < NB; ++i) {
+      double acc = (i == j) ? 1.0 : 0.0;
+      for (int c = 0; c < i; ++c) {
+        const double xv = (c >= j) ? X[lidx(c, j)] : 0.0;
+        acc -= L[lidx(i, c)] * xv;
+      }
+      if (i >= j) X[lidx(i, j)] = acc / L[lidx(i, i)];
+    }
+  }
+  __syncthreads();
+  double* Linv = Linv_all + (long long)k * NB * NB;
+  for (int e = t; e < NB * NB; e += 256) {
+    const int c = e / NB, r = e % NB;  // Linv(r, c) column-major
+    Linv[e] = (r >= c) ? X[lidx(r, c)] : 0.0;
+  }
+}
+
+// ---- fp64 matrix-core GEMM, C(i,j) (op)= sum_k A(i,k) B(j,k), column-major, 128x128 tiles ----------
+// MODE 0: trailing update  A22(i,j) -= L(i,k) L(j,k)      (tiles with j > i are skipped)
+// MODE 1: panel solve      L(i,k)   = A(i,k) Linv(k)^T    (in place: the workgroup owns the tile)
+//
+// The product is computed transposed (D[p][q] = C(i0+q, j0+p)) so that the 16 lanes sharing an
+// accumulator register hold 16 consecutive rows of one column: stores are 128-byte runs.
+constexpr int KC = 16;            // k-depth of one LDS stage
+constexpr int LDT = 128 + 16;     // LDS row pitch (doubles): the two k-groups of a half-wave land 32 banks apart
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_gemm_nt(DevP P, double* Amat, int ld, int k, const double* Linv_all) {
+  __shared__ __attribute__((aligned(16))) double sA[2][KC * LDT];  // i-tile
+  __shared__ __attribute__((aligned(16))) double sB[2][KC * LDT];  // j-tile
+  if (!P.ws[0].active || P.ws[0].solve_failed) return;
+  const int ti = k + 1 + blockIdx.x;
+  const int tj = MODE == 0 ? k + 1 + blockIdx.y : 0;
+  if (MODE == 0 && tj > ti) return;
+  const double* Ap = Amat + (long long)k * NB * ld + (long long)ti * NB;   // rows of tile i, panel columns
+  const double* Bp;
+  int ldb;
+  double* Cp;
+  if (MODE == 0) {
+    Bp = Amat + (long long)k * NB * ld + (long long)tj * NB; ldb = ld;
+    Cp = Amat + (long long)tj * NB * ld + (long long)ti * NB;
+  } else {
+    Bp = Linv_all + (long long)k * NB * NB; ldb = NB;
+    Cp = Amat + (long long)k * NB * ld + (long long)ti * NB;
+  }
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wr = wave >> 1, wc = wave & 1;  // wave's 64x64 quadrant: rows (i) wr, cols (j) wc
+  const int lcol = t >> 4, lrow = (t & 15) * 8;  // staging: column of the chunk, first of 8 rows
+
+  v4d acc[4][4];  // [j sub-tile][i sub-tile]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+  double2 ra[4], rb[4];
+  auto gload = [&](int chunk) {
+    const double* a = Ap + (long long)(chunk * KC + lcol) * ld + lrow;
+    const double* b = Bp + (long long)(chunk * KC + lcol) * ldb + lrow;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      ra[v] = reinterpret_cast<const double2*>(a)[v];
+      rb[v] = reinterpret_cast<const double2*>(b)[v];
+    }
+  };
+  auto lstore = [&](int buf) {
+    double2* a = reinterpret_cast<double2*>(&sA[buf][lcol * LDT + lrow]);
+    double2* b = reinterpret_cast<double2*>(&sB[buf][lcol * LDT + lrow]);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) { a[v] = ra[v]; b[v] = rb[v]; }
+  };
+  constexpr int nchunk = NB / KC;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int c = 0; c < nchunk; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < nchunk) gload(c + 1);
+#pragma unroll
+    for (int kk = 0; kk < KC / 4; ++kk) {
+      const int krow = (kk * 4 + (lane >> 4)) * LDT + (lane & 15);
+      double fa[4], fb[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        fa[m] = sB[buf][krow + wc * 64 + m * 16];  // MFMA a-operand: rows of the j-tile
+        fb[m] = sA[buf][krow + wr * 64 + m * 16];  // MFMA b-operand: rows of the i-tile
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
+    }
+    if (c + 1 < nchunk) lstore(buf ^ 1);
+    __syncthreads();
+  }
+  // D[p][q]: q = lane & 15 (row i within sub-tile), p = (lane >> 4) + 4 * reg (column j within sub-tile)
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int col = wc * 64 + a * 16 + (lane >> 4) + 4 * r;
+        const int row = wr * 64 + b * 16 + (lane & 15);
+        double* dst = Cp + (long long)col * ld + row;
+        if (MODE == 0) *dst -= acc[a][b][r]; else *dst = acc[a][b][r];
+      }
+    }
+  }
+}
+
+// ---- triangular solves with the blocked factor ------------------------------------------------------
+// forward step k: z_k = Linv_k b_k ; b_i -= L(i,k) z_k for every row block i > k
+__global__ __launch_bounds__(256) void k_trsv_fwd(DevP P, const double* A, int ld, int k, const double* Linv_all,
+                                                  double* rhs, double* z) {
+  __shared__ double bk[NB];
+  __shared__ double zk[NB];
+  __shared__ double part[2][NB];
+  if (!P.ws[0].active || P.ws[0].solve_failed) return;
+  const int t = threadIdx.x;
+  const double* Linv = Linv_all + (long long)k * NB * NB;
+  if (t < NB) bk[t] = rhs[k * NB + t];
+  __syncthreads();
+  {
+    const int r = t & (NB - 1), h = t >> 7;  // two threads per row, each half of the columns
+    double s = 0.0;
+    for (int c = h * (NB / 2); c < (h + 1) * (NB / 2); ++c) s += Linv[c * NB + r] * bk[c];
+    part[h][r] = s;
+  }
+  __syncthreads();
+  if (t < NB) zk[t] = part[0][t] + part[1][t];
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    if (t < NB) z[k * NB + t] = zk[t];
+    return;
+  }
+  const int i = k + blockIdx.x;
+  const double* Lik = A + (long long)k * NB * ld + (long long)i * NB;
+  {
+    const int r = t & (NB - 1), h = t >> 7;
+    double s = 0.0;
+    for (int c = h * (NB / 2); c < (h + 1) * (NB / 2); ++c) s += Lik[(long long)c * ld + r] * zk[c];
+    part[h][r] = s;
+  }
+  __syncthreads();
+  if (t < NB) rhs[i * NB + t] -= part[0][t] + part[1][t];
+}
+
+// backward step k: y_k = Linv_k^T z_k ; z_j -= L(k,j)^T y_k for every row block j < k
+__global__ __launch_bounds__(256) void k_trsv_bwd(DevP P, const double* A, int ld, int k, const double* Linv_all,
+                                                  double* z, double* y) {
+  __shared__ double zk[NB];
+  __shared__ double yk[NB];
+  if (!P.ws[0].active || P.ws[0].solve_failed) return;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const double* Linv = Linv_all + (long long)k * NB * NB;
+  if (t < NB) zk[t] = z[k * NB + t];
+  __syncthreads();
+  // y_k[c] = sum_r Linv(r, c) z_k[r]; a wave reduces one column at a time (rows contiguous)
+  for (int c = wave; c < NB; c += 4) {
+    double s = Linv[c * NB + lane] * zk[lane] + Linv[c * NB + 64 + lane] * zk[64 + lane];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) yk[c] = s;
+  }
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    if (t < NB) y[k * NB + t] = yk[t];
+    return;
+  }
+  const int j = blockIdx.x - 1;  // 0 .. k-1
+  const double* Lkj = A + (long long)j * NB * ld + (long long)k * NB;  // rows of block k, columns of block j
+  for (int c = wave; c < NB; c += 4) {
+    const double* col = Lkj + (long long)c * ld;
+    double s = col[lane] * yk[lane] + col[64 + lane] * yk[64 + lane];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) z[j * NB + c] -= s;
+  }
+}
+
+__global__ void k_store_solution(DevP P, const double* y, int n) {
+  if (!P.ws[0].active || P.ws[0].solve_failed) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double v = y[i];
+  P.yc[6ll * P.wd[0].cam_base + i] = v;
+  if (!isfinite(v)) P.ws[0].solve_failed = 1;
+}
+
+hipError_t big_solve_cholesky(const DevP& P, const BigWork& W, hipStream_t s) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_potrf_inv), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        160 * 1024 - 256);
+    attr_done = true;
+  }
+  const int n = W.n, ld = W.npad, nt = ld / NB;
+  // the number of cameras is only known on the device (P.wd); the host sized W for it
+  const int ncam = n / 6;
+  hipLaunchKernelGGL(k_unpack_lower, dim3((ncam * 36 + 255) / 256, ncam), dim3(256), 0, s, P, W.A, ld);
+  hipLaunchKernelGGL(k_pad_init, dim3((ld + 255) / 256), dim3(256), 0, s, P, W.A, W.rhs, n, ld);
+  const size_t lds = (size_t)(NB * (NB + 1)) * 8 + 64;
+  for (int k = 0; k < nt; ++k) {
+    hipLaunchKernelGGL(k_potrf_inv, dim3(1), dim3(256), lds, s, P, W.A, ld, k, W.Linv);
+    const int rest = nt - k - 1;
+    if (rest > 0) {
+      hipLaunchKernelGGL(k_gemm_nt<1>, dim3(rest), dim3(256), 0, s, P, W.A, ld, k, W.Linv);
+      hipLaunchKernelGGL(k_gemm_nt<0>, dim3(rest, rest), dim3(256), 0, s, P, W.A, ld, k, W.Linv);
+    }
+  }
+  double* z = W.rhs + ld;
+  for (int k = 0; k < nt; ++k)
+    hipLaunchKernelGGL(k_trsv_fwd, dim3(nt - k), dim3(256), 0, s, P, W.A, ld, k, W.Linv, W.rhs, z);
+  double* y = W.rhs;  // rhs is dead after the forward sweep
+  for (int k = nt - 1; k >= 0; --k)
+    hipLaunchKernelGGL(k_trsv_bwd, dim3(k + 1), dim3(256), 0, s, P, W.A, ld, k, W.Linv, z, y);
+  hipLaunchKernelGGL(k_store_solution, dim3((n + 255) / 256), dim3(256), 0, s, P, y, n);
+  return hipGetLastError();
+}
+
+// =====================================================================================================
+// block-Jacobi preconditioned conjugate gradients on the packed upper block triangle
+// =====================================================================================================
+// scalars: 0 rz, 1 bnorm2, 2 done, 3 iterations, 4 rr
+struct PcgView {
+  double *x, *r, *z, *p, *q, *scal, *part_pq, *part_rz, *part_rr;
+};
+__host__ __device__ static PcgView pcg_view(const BigWork& W, int ncam) {
+  PcgView v;
+  const size_t np = (size_t)W.npad;
+  v.x = W.pcg; v.r = v.x + np; v.z = v.r + np; v.p = v.z + np; v.q = v.p + np;
+  v.scal = v.q + 2 * np;
+  v.part_pq = v.scal + kPcgScalars;
+  v.part_rz = v.part_pq + ncam;
+  v.part_rr = v.part_rz + ncam;
+  return v;
+}
+
+// 6x6 SPD inverse by Gauss-Jordan (no pivoting needed for SPD)
+__device__ void inv6_spd(const double* Ain, double* out) {
+  double a[36];
+#pragma unroll
+  for (int i = 0; i < 36; ++i) { a[i] = Ain[i]; out[i] = (i % 7 == 0) ? 1.0 : 0.0; }
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    const double ip = 1.0 / a[7 * c];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) { a[6 * c + j] *= ip; out[6 * c + j] *= ip; }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      if (r == c) continue;
+      const double f = a[6 * r + c];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) { a[6 * r + j] -= f * a[6 * c + j]; out[6 * r + j] -= f * out[6 * c + j]; }
+    }
+  }
+}
+
+__global__ void k_pcg_init(DevP P, BigWork W, PcgView v) {
+  if (!P.ws[0].active) return;
+  const int ncam = P.wd[0].ncam;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncam) return;
+  const double* D = P.S + P.wd[0].S_off + 36ll * tri_index(c, c, ncam);
+  double Mi[36];
+  inv6_spd(D, Mi);
+  double rz = 0.0, bb = 0.0;
+  double rr[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) rr[i] = P.b[6ll * (P.wd[0].cam_base + c) + i];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    double z = 0.0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) z += Mi[6 * i + j] * rr[j];
+    v.x[6 * c + i] = 0.0; v.r[6 * c + i] = rr[i]; v.z[6 * c + i] = z; v.p[6 * c + i] = z;
+    rz += rr[i] * z; bb += rr[i] * rr[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 36; ++i) W.Minv[36ll * c + i] = Mi[i];
+  v.part_rz[c] = rz;
+  v.part_rr[c] = bb;
+}
+
+__global__ __launch_bounds__(256) void k_pcg_init2(DevP P, PcgView v, int ncam) {
+  __shared__ double red[2 * 4];
+  if (!P.ws[0].active) return;
+  double a[2] = {0.0, 0.0};
+  for (int i = threadIdx.x; i < ncam; i += 256) { a[0] += v.part_rz[i]; a[1] += v.part_rr[i]; }
+  // fixed-order block reduction
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int q = 0; q < 2; ++q) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a[q] += __shfl_xor(a[q], off);
+  }
+  if (lane == 0) { red[wave * 2] = a[0]; red[wave * 2 + 1] = a[1]; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double rz = 0.0, bb = 0.0;
+    for (int w = 0; w < 4; ++w) { rz += red[w * 2]; bb += red[w * 2 + 1]; }
+    v.scal[0] = rz; v.scal[1] = bb; v.scal[2] = (bb == 0.0) ? 1.0 : 0.0; v.scal[3] = 0.0; v.scal[4] = bb;
+  }
+}
+
+// q = S p for block row blockIdx.x, partial p.q
+__global__ __launch_bounds__(256) void k_pcg_spmv(DevP P, PcgView v) {
+  __shared__ double accU[7][36];
+  __shared__ double accL[7][36];
+  __shared__ double yrow[6];
+  if (!P.ws[0].active || v.scal[2] != 0.0) return;
+  const int ncam = P.wd[0].ncam;
+  const int r = blockIdx.x;
+  const int t = threadIdx.x;
+  const int grp = t / 36, e = t % 36;
+  const double* S = P.S + P.wd[0].S_off;
+  double au = 0.0, al = 0.0;
+  if (grp < 7) {
+    const int ea = e / 6, eb = e % 6;
+    for (int c = grp; c < ncam; c += 7) {
+      if (c >= r) {
+        const double bv = S[36ll * tri_index(r, c, ncam) + e];   // block (r,c)[ea][eb]
+        au += bv * v.p[6 * c + eb];
+      } else {
+        const double bv = S[36ll * tri_index(c, r, ncam) + e];   // block (c,r)[ea][eb] = S(6c+ea, 6r+eb)
+        al += bv * v.p[6 * c + ea];
+      }
+    }
+    accU[grp][e] = au;
+    accL[grp][e] = al;
+  }
+  __syncthreads();
+  if (t < 6) {
+    double s = 0.0;
+    for (int g = 0; g < 7; ++g) {
+      for (int b = 0; b < 6; ++b) s += accU[g][6 * t + b];   // upper: row ea = t
+      for (int a = 0; a < 6; ++a) s += accL[g][6 * a + t];   // lower (transposed): column eb = t
+    }
+    v.q[6 * r + t] = s;
+    yrow[t] = s * v.p[6 * r + t];
+  }
+  __syncthreads();
+  if (t == 0) v.part_pq[r] = yrow[0] + yrow[1] + yrow[2] + yrow[3] + yrow[4] + yrow[5];
+}
+
+__device__ __forceinline__ double sum_fixed(const double* a, int n) {
+  double s = 0.0;
+  for (int i = 0; i < n; ++i) s += a[i];
+  return s;
+}
+
+// x += alpha p ; r -= alpha q ; z = Minv r ; partials of r.z and r.r   (one thread per camera)
+__global__ __launch_bounds__(256) void k_pcg_update(DevP P, BigWork W, PcgView v, int ncam) {
+  __shared__ double s_alpha;
+  if (!P.ws[0].active || v.scal[2] != 0.0) return;
+  if (threadIdx.x == 0) {
+    // every workgroup sums the same partials in the same order
+    double pq = 0.0;
+    for (int i = 0; i < ncam; ++i) pq += v.part_pq[i];
+    s_alpha = v.scal[0] / pq;
+  }
+  __syncthreads();
+  const double alpha = s_alpha;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncam) return;
+  double rr[6];
+  double rz = 0.0, r2 = 0.0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    v.x[6 * c + i] += alpha * v.p[6 * c + i];
+    rr[i] = v.r[6 * c + i] - alpha * v.q[6 * c + i];
+    v.r[6 * c + i] = rr[i];
+    r2 += rr[i] * rr[i];
+  }
+  const double* Mi = W.Minv + 36ll * c;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    double z = 0.0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) z += Mi[6 * i + j] * rr[j];
+    v.z[6 * c + i] = z;
+    rz += rr[i] * z;
+  }
+  v.part_rz[c] = rz;
+  v.part_rr[c] = r2;
+}
+
+// beta = rz_new / rz ; p = z + beta p ; convergence test |r| <= tol |b|
+__global__ __launch_bounds__(256) void k_pcg_dir(DevP P, PcgView v, int ncam, double tol2) {
+  __shared__ double s_beta;
+  __shared__ int s_done;
+  if (!P.ws[0].active || v.scal[2] != 0.0) return;
+  if (threadIdx.x == 0) {
+    double rz = 0.0, rr = 0.0;
+    for (int i = 0; i < ncam; ++i) { rz += v.part_rz[i]; rr += v.part_rr[i]; }
+    s_beta = rz / v.scal[0];
+    s_done = (rr <= tol2 * v.scal[1]) ? 1 : 0;
+  }
+  __syncthreads();
+  const double beta = s_beta;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 6 * ncam && !s_done) v.p[i] = v.z[i] + beta * v.p[i];
+}
+
+// scalars are updated by a single-thread kernel AFTER every workgroup of k_pcg_dir has read them
+__global__ void k_pcg_commit(DevP P, PcgView v, int ncam, double tol2) {
+  if (!P.ws[0].active || v.scal[2] != 0.0) return;
+  double rz = 0.0, rr = 0.0;
+  for (int i = 0; i < ncam; ++i) { rz += v.part_rz[i]; rr += v.part_rr[i]; }
+  v.scal[0] = rz;
+  v.scal[4] = rr;
+  v.scal[3] += 1.0;
+  if (rr <= tol2 * v.scal[1] || !isfinite(rr)) v.scal[2] = 1.0;
+}
+
+__global__ void k_pcg_finish(DevP P, PcgView v, int n) {
+  if (!P.ws[0].active) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) P.ws[0].lin_iters = (int)v.scal[3];
+  if (i >= n) return;
+  const double x = v.x[i];
+  P.yc[6ll * P.wd[0].cam_base + i] = x;
+  if (!isfinite(x)) P.ws[0].solve_failed = 1;
+}
+
+hipError_t big_solve_pcg(const DevP& P, const BigWork& W, int max_iter, double tol, hipStream_t s) {
+  const int n = W.n, ncam = n / 6;
+  const PcgView v = pcg_view(W, ncam);
+  const double tol2 = tol * tol;
+  const int gc = (ncam + 255) / 256;
+  hipLaunchKernelGGL(k_pcg_init, dim3(gc), dim3(256), 0, s, P, W, v);
+  hipLaunchKernelGGL(k_pcg_init2, dim3(1), dim3(256), 0, s, P, v, ncam);
+  double done = 0.0;
+  for (int it = 0; it < max_iter; ++it) {
+    hipLaunchKernelGGL(k_pcg_spmv, dim3(ncam), dim3(256), 0, s, P, v);
+    hipLaunchKernelGGL(k_pcg_update, dim3(gc), dim3(256), 0, s, P, W, v, ncam);
+    hipLaunchKernelGGL(k_pcg_dir, dim3((6 * ncam + 255) / 256), dim3(256), 0, s, P, v, ncam, tol2);
+    hipLaunchKernelGGL(k_pcg_commit, dim3(1), dim3(1), 0, s, P, v, ncam, tol2);
+    if ((it % 16) == 15) {
+      hipError_t e = hipMemcpyAsync(&done, v.scal + 2, sizeof(double), hipMemcpyDeviceToHost, s);
+      if (e != hipSuccess) return e;
+      e = hipStreamSynchronize(s);
+      if (e != hipSuccess) return e;
+      if (done != 0.0) break;
+    }
+  }
+  hipLaunchKernelGGL(k_pcg_finish, dim3((n + 255) / 256), dim3(256), 0, s, P, v, n);
+  return hipGetLastError();
+}
+
+}  // namespace hipba

@@ -1,0 +1,1063 @@
+// hipba_api.hip -- the C ABI of include/hipba.h: problem analysis on the host, residency
+// management and the host side of the Levenberg-Marquardt loop.
+//
+// The host does what ceres::Problem / Program preprocessing does for the reference
+// (src/solve/optimizer.cpp:16-52): it drops constant and unobserved blocks, classifies
+// residual blocks, and lays everything out as flat arrays.  The per-iteration arithmetic
+// and the accept/reject logic run in lm_kernels.hip; the host only queues kernels and
+// polls one integer (the number of windows still iterating) per iteration.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "hipba_internal.hpp"
+
+using namespace hipba;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+#define HIPBA_HIP(expr)                                                                               \
+  do {                                                                                                \
+    hipError_t e__ = (expr);                                                                          \
+    if (e__ != hipSuccess)                                                                            \
+      return fail(e__ == hipErrorOutOfMemory ? HIPBA_ERR_OUT_OF_MEMORY : HIPBA_ERR_HIP, "%s: %s (%s:%d)", #expr, \
+                  hipGetErrorString(e__), __FILE__, __LINE__);                                        \
+  } while (0)
+
+double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+struct hipba_handle_s {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  // grow-only buffers reused by hipba_solve / hipba_solve_batched
+  void* arena = nullptr;
+  size_t arena_bytes = 0;
+  void* staging = nullptr;  // pinned host memory
+  size_t staging_bytes = 0;
+  int* h_count = nullptr;   // pinned: windows still active
+};
+
+struct WinMeta {
+  int n_poses = 0, n_points = 0;
+  long long n_obs = 0;
+  int pose_base = 0;
+  int n_act_poses = 0, n_act_points = 0;
+  long long n_act_obs = 0;
+  std::vector<int> dp_of;  // original landmark index -> device landmark index
+};
+
+struct hipba_device_problem_s {
+  void* arena = nullptr;
+  size_t arena_bytes = 0;
+  bool owns_arena = false;
+  DevP P{};
+  std::vector<WinMeta> meta;
+  double* poses0 = nullptr;   // uploaded parameters, kept for hipba_reset
+  double* points0 = nullptr;
+  int* d_count = nullptr;
+  int max_ncam = 0;
+  int n_blocks = 0;
+  long long S_doubles = 0;
+  BigWork big;
+  bool has_big = false;
+};
+
+namespace {
+
+// ---- arena planning ----------------------------------------------------------------------------
+struct ArenaPlan {
+  struct Item { void** dst; size_t bytes; size_t off; };
+  std::vector<Item> items;
+  size_t total = 0;
+  template <typename T>
+  void add(T** dst, size_t count) {
+    Item it;
+    it.dst = reinterpret_cast<void**>(dst);
+    it.bytes = count * sizeof(T);
+    it.off = total;
+    total = align_up(total + std::max<size_t>(it.bytes, 16), 256);
+    items.push_back(it);
+  }
+  void bind(void* base) {
+    for (auto& it : items) *it.dst = static_cast<char*>(base) + it.off;
+  }
+};
+
+int ensure_arena(hipba_handle_s* h, size_t bytes) {
+  if (h->arena_bytes >= bytes) return HIPBA_OK;
+  if (h->arena) { HIPBA_HIP(hipFree(h->arena)); h->arena = nullptr; h->arena_bytes = 0; }
+  const size_t want = align_up(bytes + bytes / 4, 1 << 20);
+  HIPBA_HIP(hipMalloc(&h->arena, want));
+  h->arena_bytes = want;
+  return HIPBA_OK;
+}
+
+int ensure_staging(hipba_handle_s* h, size_t bytes) {
+  if (h->staging_bytes >= bytes) return HIPBA_OK;
+  if (h->staging) { HIPBA_HIP(hipHostFree(h->staging)); h->staging = nullptr; h->staging_bytes = 0; }
+  const size_t want = align_up(bytes + bytes / 4, 1 << 20);
+  HIPBA_HIP(hipHostMalloc(&h->staging, want, hipHostMallocDefault));
+  h->staging_bytes = want;
+  return HIPBA_OK;
+}
+
+LmParams make_lm(const hipba_options& o) {
+  LmParams lm;
+  lm.max_num_iterations = o.max_num_iterations;
+  lm.loss = o.loss;
+  lm.loss_scale = o.loss_scale;
+  lm.jacobi_scaling = o.jacobi_scaling;
+  lm.max_invalid = o.max_num_consecutive_invalid_steps;
+  lm.max_radius = o.max_trust_region_radius;
+  lm.min_radius = o.min_trust_region_radius;
+  lm.min_relative_decrease = o.min_relative_decrease;
+  lm.min_lm_diagonal = o.min_lm_diagonal;
+  lm.max_lm_diagonal = o.max_lm_diagonal;
+  lm.function_tolerance = o.function_tolerance;
+  lm.gradient_tolerance = o.gradient_tolerance;
+  lm.parameter_tolerance = o.parameter_tolerance;
+  lm.initial_radius = o.initial_trust_region_radius;
+  return lm;
+}
+
+int validate_problem(const hipba_problem& p, int w) {
+  if (p.n_poses < 0 || p.n_points < 0 || p.n_obs < 0) return fail(HIPBA_ERR_INVALID_ARGUMENT, "window %d: negative size", w);
+  if ((p.n_poses && !p.poses) || (p.n_points && !p.points))
+    return fail(HIPBA_ERR_INVALID_ARGUMENT, "window %d: null parameter array", w);
+  if (p.n_obs && (!p.obs_pose || !p.obs_point || !p.obs_uv))
+    return fail(HIPBA_ERR_INVALID_ARGUMENT, "window %d: null observation array", w);
+  if (p.camera_model != HIPBA_CAMERA_Z_FORWARD && p.camera_model != HIPBA_CAMERA_X_FORWARD)
+    return fail(HIPBA_ERR_INVALID_ARGUMENT, "window %d: unknown camera model %d", w, p.camera_model);
+  for (long long k = 0; k < p.n_obs; ++k) {
+    if (p.obs_pose[k] < 0 || p.obs_pose[k] >= p.n_poses || p.obs_point[k] < 0 || p.obs_point[k] >= p.n_points)
+      return fail(HIPBA_ERR_INVALID_ARGUMENT, "window %d: observation %lld references pose %d / landmark %d out of range",
+                  w, k, p.obs_pose[k], p.obs_point[k]);
+  }
+  return HIPBA_OK;
+}
+
+// ---- analysis + upload -------------------------------------------------------------------------
+int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool use_handle_arena, int log_cap,
+                   bool all_poses_active, hipba_device_problem_s** out) {
+  for (int w = 0; w < nw; ++w) {
+    int rc = validate_problem(probs[w], w);
+    if (rc) return rc;
+  }
+  auto* R = new hipba_device_problem_s();
+  R->meta.resize(nw);
+  DevP& P = R->P;
+  P = DevP{};
+  P.n_windows = nw;
+
+  long long NP = 0, NPT = 0, NO = 0;
+  for (int w = 0; w < nw; ++w) {
+    R->meta[w].n_poses = probs[w].n_poses;
+    R->meta[w].n_points = probs[w].n_points;
+    R->meta[w].n_obs = probs[w].n_obs;
+    R->meta[w].pose_base = (int)NP;
+    NP += probs[w].n_poses; NPT += probs[w].n_points; NO += probs[w].n_obs;
+  }
+  if (NP > 0x7fffffffLL / 8 || NPT > 0x7fffffffLL / 4) { delete R; return fail(HIPBA_ERR_UNSUPPORTED, "problem too large for 32-bit block indices"); }
+
+  // per landmark / pose bookkeeping
+  std::vector<long long> pt_base(nw + 1, 0);
+  for (int w = 0; w < nw; ++w) pt_base[w + 1] = pt_base[w] + probs[w].n_points;
+  std::vector<int> deg(NPT, 0);          // observations of a variable landmark
+  std::vector<int> pose_nobs(NP, 0);
+  std::vector<uint8_t> pose_c(NP, 0), pt_c(NPT, 0);
+  for (int w = 0; w < nw; ++w) {
+    const hipba_problem& p = probs[w];
+    for (int i = 0; i < p.n_poses; ++i) pose_c[R->meta[w].pose_base + i] = p.pose_const ? (p.pose_const[i] != 0) : 0;
+    for (int i = 0; i < p.n_points; ++i) pt_c[pt_base[w] + i] = p.point_const ? (p.point_const[i] != 0) : 0;
+    for (long long k = 0; k < p.n_obs; ++k) {
+      const long long gp = pt_base[w] + p.obs_point[k];
+      if (!pt_c[gp]) deg[gp]++;
+      pose_nobs[R->meta[w].pose_base + p.obs_pose[k]]++;
+    }
+  }
+  // device landmark order: variable observed landmarks first (by window, index), the rest after
+  std::vector<int> dp_of(NPT, -1);
+  std::vector<WinDesc> wd(nw);
+  int n_pm_points = 0;
+  for (int w = 0; w < nw; ++w) {
+    wd[w] = WinDesc{};
+    wd[w].pp_begin = n_pm_points;
+    for (int i = 0; i < probs[w].n_points; ++i) {
+      const long long gp = pt_base[w] + i;
+      if (deg[gp] > 0) {
+        if (deg[gp] > HIPBA_MAX_POINT_DEGREE) {
+          delete R;
+          return fail(HIPBA_ERR_UNSUPPORTED, "window %d: landmark %d has %d observations (limit %d)", w, i, deg[gp],
+                      HIPBA_MAX_POINT_DEGREE);
+        }
+        dp_of[gp] = n_pm_points++;
+      }
+    }
+    wd[w].pp_end = n_pm_points;
+    R->meta[w].n_act_points = wd[w].pp_end - wd[w].pp_begin;
+  }
+  {
+    int next = n_pm_points;
+    for (long long gp = 0; gp < NPT; ++gp)
+      if (dp_of[gp] < 0) dp_of[gp] = next++;
+  }
+  // global slots of variable observed poses
+  std::vector<int> pose_gslot(NP, -1), pose_window(NP, 0), slot_pose;
+  int n_slots = 0, max_ncam = 0;
+  long long S_doubles = 0;
+  for (int w = 0; w < nw; ++w) {
+    const hipba_problem& p = probs[w];
+    wd[w].K = CameraK{p.fx, p.fy, p.cx, p.cy, p.camera_model};
+    wd[w].pose_begin = R->meta[w].pose_base;
+    wd[w].pose_end = wd[w].pose_begin + p.n_poses;
+    wd[w].cam_base = n_slots;
+    for (int i = 0; i < p.n_poses; ++i) {
+      const int c = wd[w].pose_begin + i;
+      pose_window[c] = w;
+      // a shard keeps every variable pose so that all ranks agree on the layout of the reduced system
+      if (!pose_c[c] && (pose_nobs[c] > 0 || all_poses_active)) { pose_gslot[c] = n_slots++; slot_pose.push_back(c); }
+    }
+    wd[w].ncam = n_slots - wd[w].cam_base;
+    R->meta[w].n_act_poses = wd[w].ncam;
+    max_ncam = std::max(max_ncam, wd[w].ncam);
+    wd[w].S_off = S_doubles;
+    S_doubles += 36ll * wd[w].ncam * (wd[w].ncam + 1) / 2;
+    wd[w].log_base = w * log_cap;
+  }
+  if (max_ncam * 6 > kSmallMaxN && nw > 1) {
+    delete R;
+    return fail(HIPBA_ERR_UNSUPPORTED, "batched windows are limited to %d variable poses each (got %d)", kSmallMaxN / 6,
+                max_ncam);
+  }
+
+  // ---- observations: PM | VC | CC --------------------------------------------------------------
+  std::vector<long long> pp_start(n_pm_points + 1, 0);
+  for (long long gp = 0; gp < NPT; ++gp)
+    if (deg[gp] > 0) pp_start[dp_of[gp] + 1] = deg[gp];
+  for (int i = 0; i < n_pm_points; ++i) pp_start[i + 1] += pp_start[i];
+  const long long n_pm_obs = pp_start[n_pm_points];
+  long long n_vc = 0, n_cc = 0;
+  for (int w = 0; w < nw; ++w) {
+    const hipba_problem& p = probs[w];
+    for (long long k = 0; k < p.n_obs; ++k) {
+      const long long gp = pt_base[w] + p.obs_point[k];
+      if (pt_c[gp]) {
+        if (pose_c[R->meta[w].pose_base + p.obs_pose[k]]) ++n_cc; else ++n_vc;
+      }
+    }
+  }
+  const long long n_act_obs = n_pm_obs + n_vc, n_all = n_act_obs + n_cc;
+  std::vector<int> obs_pose(std::max<long long>(n_all, 1)), obs_dp(std::max<long long>(n_all, 1));
+  std::vector<double> obs_uv(std::max<long long>(2 * n_all, 2));
+  std::vector<int> vc_window_count(nw, 0), cc_window_count(nw, 0);
+  {
+    std::vector<long long> cur(pp_start.begin(), pp_start.end() - 1);
+    long long vc_cur = n_pm_obs, cc_cur = n_act_obs;
+    for (int w = 0; w < nw; ++w) {
+      const hipba_problem& p = probs[w];
+      for (long long k = 0; k < p.n_obs; ++k) {
+        const long long gp = pt_base[w] + p.obs_point[k];
+        const int c = R->meta[w].pose_base + p.obs_pose[k];
+        long long dst;
+        if (!pt_c[gp]) dst = cur[dp_of[gp]]++;
+        else if (!pose_c[c]) { dst = vc_cur++; vc_window_count[w]++; }
+        else { dst = cc_cur++; cc_window_count[w]++; }
+        obs_pose[dst] = c;
+        obs_dp[dst] = dp_of[gp];
+        obs_uv[2 * dst] = p.obs_uv[2 * k];
+        obs_uv[2 * dst + 1] = p.obs_uv[2 * k + 1];
+      }
+      R->meta[w].n_act_obs = 0;
+    }
+    // sort each landmark's segment by pose index (stable) so that slots increase along a segment
+    for (int pp = 0; pp < n_pm_points; ++pp) {
+      const long long s0 = pp_start[pp], s1 = pp_start[pp + 1];
+      for (long long i = s0 + 1; i < s1; ++i) {
+        const int cp = obs_pose[i];
+        const double u = obs_uv[2 * i], v = obs_uv[2 * i + 1];
+        long long j = i - 1;
+        while (j >= s0 && obs_pose[j] > cp) {
+          obs_pose[j + 1] = obs_pose[j];
+          obs_uv[2 * (j + 1)] = obs_uv[2 * j]; obs_uv[2 * (j + 1) + 1] = obs_uv[2 * j + 1];
+          --j;
+        }
+        obs_pose[j + 1] = cp; obs_uv[2 * (j + 1)] = u; obs_uv[2 * (j + 1) + 1] = v;
+      }
+    }
+  }
+
+  // ---- blocks + pair lists -----------------------------------------------------------------------
+  std::vector<BlockDesc> blocks;
+  std::vector<unsigned short> pairs;
+  for (int w = 0; w < nw; ++w) {
+    wd[w].pm_blk_begin = (int)blocks.size();
+    int pp = wd[w].pp_begin;
+    while (pp < wd[w].pp_end) {
+      BlockDesc d{};
+      d.obs_begin = pp_start[pp];
+      d.pair_begin = (long long)pairs.size();
+      d.window = w;
+      d.kind = 0;
+      int n = 0;
+      while (pp < wd[w].pp_end && n + (int)(pp_start[pp + 1] - pp_start[pp]) <= kBlock) {
+        const int s0 = n, s1 = n + (int)(pp_start[pp + 1] - pp_start[pp]);
+        for (int i = s0; i < s1; ++i) {
+          if (pose_gslot[obs_pose[d.obs_begin + i]] < 0) continue;
+          for (int j = i; j < s1; ++j) {
+            if (pose_gslot[obs_pose[d.obs_begin + j]] < 0) continue;
+            pairs.push_back((unsigned short)(i | (j << 8)));
+          }
+        }
+        n = s1;
+        ++pp;
+      }
+      d.n_obs = n;
+      d.n_pairs = (int)((long long)pairs.size() - d.pair_begin);
+      blocks.push_back(d);
+    }
+    wd[w].pm_blk_end = (int)blocks.size();
+  }
+  const int n_blk_pm = (int)blocks.size();
+  {
+    long long cur = n_pm_obs;
+    for (int w = 0; w < nw; ++w) {
+      wd[w].vc_blk_begin = (int)blocks.size();
+      for (int left = vc_window_count[w]; left > 0;) {
+        BlockDesc d{};
+        d.obs_begin = cur; d.n_obs = std::min(left, kBlock); d.window = w; d.kind = 1;
+        blocks.push_back(d);
+        cur += d.n_obs; left -= d.n_obs;
+      }
+      wd[w].vc_blk_end = (int)blocks.size();
+    }
+  }
+  const int n_blk_vc = (int)blocks.size() - n_blk_pm;
+  {
+    long long cur = n_act_obs;
+    for (int w = 0; w < nw; ++w) {
+      wd[w].cc_blk_begin = (int)blocks.size();
+      for (int left = cc_window_count[w]; left > 0;) {
+        BlockDesc d{};
+        d.obs_begin = cur; d.n_obs = std::min(left, kBlock); d.window = w; d.kind = 2;
+        blocks.push_back(d);
+        cur += d.n_obs; left -= d.n_obs;
+      }
+      wd[w].cc_blk_end = (int)blocks.size();
+    }
+  }
+  const int n_blk_cc = (int)blocks.size() - n_blk_pm - n_blk_vc;
+  const int n_blocks = (int)blocks.size();
+
+  // ---- camera-major lists ------------------------------------------------------------------------
+  std::vector<long long> cm_start(n_slots + 1, 0);
+  for (long long o = 0; o < n_act_obs; ++o) {
+    const int g = pose_gslot[obs_pose[o]];
+    if (g >= 0) cm_start[g + 1]++;
+  }
+  for (int g = 0; g < n_slots; ++g) cm_start[g + 1] += cm_start[g];
+  const long long n_cm = cm_start[n_slots];
+  std::vector<int> cm_dp(std::max<long long>(n_cm, 1));
+  std::vector<double> cm_uv(std::max<long long>(2 * n_cm, 2));
+  {
+    std::vector<long long> cur(cm_start.begin(), cm_start.end() - 1);
+    for (long long o = 0; o < n_act_obs; ++o) {
+      const int g = pose_gslot[obs_pose[o]];
+      if (g < 0) continue;
+      const long long dst = cur[g]++;
+      cm_dp[dst] = obs_dp[o];
+      cm_uv[2 * dst] = obs_uv[2 * o]; cm_uv[2 * dst + 1] = obs_uv[2 * o + 1];
+    }
+  }
+  for (int w = 0; w < nw; ++w) {
+    long long na = 0;
+    for (int b = wd[w].pm_blk_begin; b < wd[w].pm_blk_end; ++b) na += blocks[b].n_obs;
+    for (int b = wd[w].vc_blk_begin; b < wd[w].vc_blk_end; ++b) na += blocks[b].n_obs;
+    R->meta[w].n_act_obs = na;
+    R->meta[w].dp_of.assign(dp_of.begin() + pt_base[w], dp_of.begin() + pt_base[w + 1]);
+  }
+
+  // ---- parameters in device order ----------------------------------------------------------------
+  std::vector<double> poses(std::max<long long>(7 * NP, 7)), points(std::max<long long>(3 * NPT, 3));
+  for (int w = 0; w < nw; ++w) {
+    const hipba_problem& p = probs[w];
+    if (p.n_poses) memcpy(poses.data() + 7ll * R->meta[w].pose_base, p.poses, sizeof(double) * 7 * p.n_poses);
+    for (int i = 0; i < p.n_points; ++i) {
+      const int dp = dp_of[pt_base[w] + i];
+      points[3ll * dp] = p.points[3 * i]; points[3ll * dp + 1] = p.points[3 * i + 1]; points[3ll * dp + 2] = p.points[3 * i + 2];
+    }
+  }
+
+  // ---- plan the arena ----------------------------------------------------------------------------
+  P.n_poses = (int)NP; P.n_points = (int)NPT; P.n_act_poses = n_slots; P.n_pm_points = n_pm_points;
+  P.n_pm_obs = n_pm_obs; P.n_act_obs = n_act_obs; P.n_all_obs = n_all;
+  P.n_blk_pm = n_blk_pm; P.n_blk_vc = n_blk_vc; P.n_blk_cc = n_blk_cc;
+  P.log_cap = log_cap;
+  R->max_ncam = max_ncam; R->n_blocks = n_blocks; R->S_doubles = S_doubles;
+
+  ArenaPlan up;  // uploaded region (one host->device copy)
+  int *d_pose_window, *d_pose_gslot, *d_slot_pose, *d_cm_dp, *d_obs_pose, *d_obs_dp;
+  long long *d_cm_start, *d_pp_start;
+  double *d_cm_uv, *d_obs_uv;
+  BlockDesc* d_blocks; unsigned short* d_pairs; WinDesc* d_wd;
+  up.add(&P.poses[0], poses.size());
+  up.add(&P.points[0], points.size());
+  up.add(&d_pose_window, std::max<size_t>(pose_window.size(), 1));
+  up.add(&d_pose_gslot, std::max<size_t>(pose_gslot.size(), 1));
+  up.add(&d_slot_pose, std::max<size_t>(slot_pose.size(), 1));
+  up.add(&d_cm_start, cm_start.size());
+  up.add(&d_cm_dp, cm_dp.size());
+  up.add(&d_cm_uv, cm_uv.size());
+  up.add(&d_obs_pose, obs_pose.size());
+  up.add(&d_obs_dp, obs_dp.size());
+  up.add(&d_obs_uv, obs_uv.size());
+  up.add(&d_pp_start, pp_start.size());
+  up.add(&d_blocks, std::max<size_t>(blocks.size(), 1));
+  up.add(&d_pairs, std::max<size_t>(pairs.size(), 1));
+  up.add(&d_wd, wd.size());
+  const size_t upload_bytes = up.total;
+  ArenaPlan work = up;  // continues after the uploaded region
+  work.items.clear();
+  const size_t ns = std::max(n_slots, 1), npp = std::max(n_pm_points, 1);
+  work.add(&P.poses[1], poses.size());
+  work.add(&P.points[1], points.size());
+  work.add(&R->poses0, poses.size());
+  work.add(&R->points0, points.size());
+  work.add(&P.ws, (size_t)nw);
+  work.add(&P.U, 36 * ns);
+  work.add(&P.gc, 6 * ns);
+  work.add(&P.scale_c, 6 * ns);
+  work.add(&P.b, 6 * ns);
+  work.add(&P.yc, 6 * ns);
+  work.add(&P.Vinv, 6 * npp);
+  work.add(&P.gp, 3 * npp);
+  work.add(&P.scale_p, 3 * npp);
+  work.add(&P.S, (size_t)std::max<long long>(S_doubles, 1));
+  work.add(&P.partial, (size_t)2 * kPartialStride * std::max(n_blocks, 1));
+  work.add(&P.gpart, (size_t)2 * std::max(n_blk_pm, 1));
+  work.add(&P.wsum, (size_t)8 * nw);
+  work.add(&P.log, (size_t)std::max(log_cap, 1) * nw);
+  work.add(&R->d_count, 4);
+  char* big_base_dummy = nullptr;
+  size_t big_bytes = 0;
+  if (6 * max_ncam > kSmallMaxN) {
+    big_bytes = big_work_bytes(6 * max_ncam, max_ncam);
+    work.add(&big_base_dummy, big_bytes);
+    R->has_big = true;
+  }
+  const size_t total = work.total;
+
+  // ---- allocate + upload -------------------------------------------------------------------------
+  int rc = HIPBA_OK;
+  if (use_handle_arena) {
+    rc = ensure_arena(h, total);
+    if (rc) { delete R; return rc; }
+    R->arena = h->arena; R->owns_arena = false;
+  } else {
+    hipError_t e = hipMalloc(&R->arena, total);
+    if (e != hipSuccess) { delete R; return fail(HIPBA_ERR_OUT_OF_MEMORY, "hipMalloc(%zu bytes): %s", total, hipGetErrorString(e)); }
+    R->owns_arena = true;
+  }
+  R->arena_bytes = total;
+  auto cleanup = [&]() {
+    if (R->owns_arena && R->arena) (void)hipFree(R->arena);
+    delete R;
+  };
+  rc = ensure_staging(h, upload_bytes);
+  if (rc) { cleanup(); return rc; }
+  up.bind(R->arena);
+  work.bind(R->arena);
+  if (R->has_big) big_work_bind(R->big, 6 * max_ncam, max_ncam, big_base_dummy);
+  P.pose_window = d_pose_window; P.pose_gslot = d_pose_gslot; P.slot_pose = d_slot_pose;
+  P.cm_start = d_cm_start; P.cm_dp = d_cm_dp; P.cm_uv = d_cm_uv;
+  P.obs_pose = d_obs_pose; P.obs_dp = d_obs_dp; P.obs_uv = d_obs_uv; P.pp_obs_start = d_pp_start;
+  P.blocks = d_blocks; P.pairs = d_pairs; P.wd = d_wd;
+
+  char* st = static_cast<char*>(h->staging);
+  auto stage = [&](const void* dev_ptr, const void* src, size_t bytes) {
+    if (bytes) memcpy(st + (static_cast<const char*>(dev_ptr) - static_cast<const char*>(R->arena)), src, bytes);
+  };
+  stage(P.poses[0], poses.data(), poses.size() * 8);
+  stage(P.points[0], points.data(), points.size() * 8);
+  stage(d_pose_window, pose_window.data(), pose_window.size() * 4);
+  stage(d_pose_gslot, pose_gslot.data(), pose_gslot.size() * 4);
+  stage(d_slot_pose, slot_pose.data(), slot_pose.size() * 4);
+  stage(d_cm_start, cm_start.data(), cm_start.size() * 8);
+  stage(d_cm_dp, cm_dp.data(), cm_dp.size() * 4);
+  stage(d_cm_uv, cm_uv.data(), cm_uv.size() * 8);
+  stage(d_obs_pose, obs_pose.data(), obs_pose.size() * 4);
+  stage(d_obs_dp, obs_dp.data(), obs_dp.size() * 4);
+  stage(d_obs_uv, obs_uv.data(), obs_uv.size() * 8);
+  stage(d_pp_start, pp_start.data(), pp_start.size() * 8);
+  stage(d_blocks, blocks.data(), blocks.size() * sizeof(BlockDesc));
+  stage(d_pairs, pairs.data(), pairs.size() * 2);
+  stage(d_wd, wd.data(), wd.size() * sizeof(WinDesc));
+  hipStream_t s = h->stream;
+  hipError_t e = hipMemcpyAsync(R->arena, h->staging, upload_bytes, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(P.poses[1], P.poses[0], poses.size() * 8, hipMemcpyDeviceToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(P.points[1], P.points[0], points.size() * 8, hipMemcpyDeviceToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(R->poses0, P.poses[0], poses.size() * 8, hipMemcpyDeviceToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(R->points0, P.points[0], points.size() * 8, hipMemcpyDeviceToDevice, s);
+  if (e == hipSuccess) e = hipMemsetAsync(P.ws, 0, sizeof(WinState) * nw, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);  // staging is reused by the next call
+  if (e != hipSuccess) { cleanup(); return fail(HIPBA_ERR_HIP, "upload failed: %s", hipGetErrorString(e)); }
+  *out = R;
+  return HIPBA_OK;
+}
+
+void print_progress(const hipba_iteration* log, int n) {
+  printf("iter      cost      cost_change  |gradient|   |step|    tr_ratio  tr_radius  ls_iter\n");
+  for (int i = 0; i < n; ++i) {
+    const hipba_iteration& it = log[i];
+    printf("%4d % .6e  % .2e   %.2e   %.2e  % .2e   %.2e   %4d%s\n", it.iteration, it.cost, it.cost_change,
+           it.gradient_max_norm, it.step_norm, it.relative_decrease, it.trust_region_radius,
+           it.linear_solver_iterations, it.step_is_successful ? "" : (it.step_is_valid ? "  (rejected)" : "  (invalid)"));
+  }
+}
+
+// ---- the LM loop ---------------------------------------------------------------------------------
+int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o, const hipba_comm* comm,
+           hipba_summary* summaries) {
+  const double t0 = now_s();
+  DevP P = R->P;
+  hipStream_t s = h->stream;
+  const LmParams lm = make_lm(o);
+  const bool sharded = comm && comm->world_size > 1;
+  if (sharded && P.n_windows != 1) return fail(HIPBA_ERR_INVALID_ARGUMENT, "sharded solves take exactly one window");
+  if (sharded && !comm->allreduce) return fail(HIPBA_ERR_INVALID_ARGUMENT, "comm->allreduce is null");
+  P.sharded = sharded ? 1 : 0;
+  const int owner = (!sharded || comm->rank == 0) ? 1 : 0;
+  const int n_act_blk = P.n_blk_pm + P.n_blk_vc;
+  const int max_n = 6 * R->max_ncam;
+  const bool small = max_n <= kSmallMaxN;
+  int solver = o.linear_solver;
+  if (small) solver = HIPBA_LINEAR_DENSE_CHOLESKY;
+  else if (solver == HIPBA_LINEAR_AUTO) solver = HIPBA_LINEAR_DENSE_CHOLESKY;
+  // LDS accumulation of the reduced matrix pays when a window's packed S is small
+  int lds_acc_ncam = 0;
+  if (R->max_ncam > 0 && R->max_ncam <= 20 && !sharded) lds_acc_ncam = R->max_ncam;
+
+  auto allreduce = [&](double* buf, size_t n, int op) -> int {
+    if (!sharded) return 0;
+    return comm->allreduce(comm->ctx, buf, n, op, (void*)s);
+  };
+#define AR(buf, n, op)                                                                  \
+  do {                                                                                  \
+    if (allreduce((buf), (n), (op))) return fail(HIPBA_ERR_COMM, "all-reduce callback failed"); \
+  } while (0)
+
+  // iteration 0: cost at the starting point, fixed cost, Jacobi scaling
+  HIPBA_HIP(launch_cost(P, lm, 0, n_act_blk, 0, 1, false, s));
+  HIPBA_HIP(launch_cost(P, lm, n_act_blk, P.n_blk_cc, 0, 1, false, s));
+  if (sharded) {
+    HIPBA_HIP(launch_window_init(P, lm, kReduce, s));
+    // fixed cost belongs to the rank that owns the pose-only blocks; every rank evaluates the same CC
+    // list only if it was given one, so the sum is what the caller sharded
+    AR(P.wsum, 3, HIPBA_REDUCE_SUM);
+    HIPBA_HIP(launch_window_init(P, lm, kDecide, s));
+  } else {
+    HIPBA_HIP(launch_window_init(P, lm, kFused, s));
+  }
+  HIPBA_HIP(launch_camera_blocks(P, lm, 0, s));
+  if (sharded && P.n_act_poses) { AR(P.U, 36 * (size_t)P.n_act_poses, HIPBA_REDUCE_SUM); AR(P.gc, 6 * (size_t)P.n_act_poses, HIPBA_REDUCE_SUM); }
+  HIPBA_HIP(launch_make_scale_c(P, lm.jacobi_scaling, s));
+  HIPBA_HIP(launch_point_colnorm(P, lm, s));
+
+  int iterations_run = 0;
+  for (int iter = 1; iter <= std::max(lm.max_num_iterations, 0); ++iter) {
+    if (iter > 1) {
+      HIPBA_HIP(launch_camera_blocks(P, lm, 1, s));
+      if (sharded && P.n_act_poses) { AR(P.U, 36 * (size_t)P.n_act_poses, HIPBA_REDUCE_SUM); AR(P.gc, 6 * (size_t)P.n_act_poses, HIPBA_REDUCE_SUM); }
+    }
+    if (R->S_doubles) HIPBA_HIP(hipMemsetAsync(P.S, 0, sizeof(double) * (size_t)R->S_doubles, s));
+    HIPBA_HIP(launch_init_reduced(P, lm, owner, s));
+    HIPBA_HIP(launch_point_schur(P, lm, lds_acc_ncam, s));
+    if (sharded) {
+      if (R->S_doubles) AR(P.S, (size_t)R->S_doubles, HIPBA_REDUCE_SUM);
+      if (P.n_act_poses) AR(P.b, 6 * (size_t)P.n_act_poses, HIPBA_REDUCE_SUM);
+      HIPBA_HIP(launch_window_gradient(P, lm, kReduce, s));
+      AR(P.wsum, 1, HIPBA_REDUCE_MAX);
+      AR(P.wsum + 1, 1, HIPBA_REDUCE_SUM);
+      HIPBA_HIP(launch_window_gradient(P, lm, kDecide, s));
+    }
+    if (small && !sharded) {
+      HIPBA_HIP(launch_window_solve_small(P, lm, max_n, s));
+    } else {
+      if (!sharded) HIPBA_HIP(launch_window_gradient(P, lm, kFused, s));
+      if (small) {
+        // sharded small window: gradient already decided; the LDS solver repeats the (idempotent) check
+        HIPBA_HIP(launch_window_solve_small(P, lm, max_n, s));
+      } else if (solver == HIPBA_LINEAR_PCG) {
+        HIPBA_HIP(big_solve_pcg(P, R->big, o.pcg_max_iterations, o.pcg_tolerance, s));
+      } else {
+        HIPBA_HIP(big_solve_cholesky(P, R->big, s));
+      }
+    }
+    HIPBA_HIP(launch_backsub(P, lm, s));
+    HIPBA_HIP(launch_pose_update(P, s));
+    HIPBA_HIP(launch_cost(P, lm, 0, n_act_blk, 1, 0, true, s));
+    if (sharded) {
+      HIPBA_HIP(launch_window_control(P, lm, kReduce, s));
+      AR(P.wsum, 5, HIPBA_REDUCE_SUM);
+      HIPBA_HIP(launch_window_control(P, lm, kDecide, s));
+    } else {
+      HIPBA_HIP(launch_window_control(P, lm, kFused, s));
+    }
+    iterations_run = iter;
+    HIPBA_HIP(launch_count_active(P, R->d_count, s));
+    HIPBA_HIP(hipMemcpyAsync(h->h_count, R->d_count, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPBA_HIP(hipStreamSynchronize(s));
+    if (*h->h_count == 0) break;
+  }
+#undef AR
+  (void)iterations_run;
+  HIPBA_HIP(hipStreamSynchronize(s));
+  const double t1 = now_s();
+
+  // summaries
+  std::vector<WinState> ws(P.n_windows);
+  HIPBA_HIP(hipMemcpy(ws.data(), P.ws, sizeof(WinState) * P.n_windows, hipMemcpyDeviceToHost));
+  std::vector<hipba_iteration> log;
+  bool want_log = o.minimizer_progress_to_stdout != 0;
+  for (int w = 0; w < P.n_windows && !want_log; ++w) want_log = summaries[w].iteration_log != nullptr;
+  if (want_log && P.log_cap > 0) {
+    log.resize((size_t)P.log_cap * P.n_windows);
+    HIPBA_HIP(hipMemcpy(log.data(), P.log, sizeof(hipba_iteration) * log.size(), hipMemcpyDeviceToHost));
+  }
+  for (int w = 0; w < P.n_windows; ++w) {
+    hipba_summary& sm = summaries[w];
+    hipba_iteration* user_log = sm.iteration_log;
+    const int user_cap = sm.iteration_log_capacity;
+    const WinState& st = ws[w];
+    int term = st.termination;
+    if (st.active) term = HIPBA_NO_CONVERGENCE;  // loop ended on max_num_iterations on the host side
+    sm.termination_type = term;
+    sm.num_iterations = st.iteration + 1;
+    sm.num_successful_steps = st.num_successful;
+    sm.num_unsuccessful_steps = st.num_unsuccessful;
+    sm.initial_cost = st.initial_cost;
+    sm.final_cost = st.x_cost + st.fixed_cost;
+    sm.fixed_cost = st.fixed_cost;
+    sm.num_active_poses = R->meta[w].n_act_poses;
+    sm.num_active_points = R->meta[w].n_act_points;
+    sm.num_active_observations = R->meta[w].n_act_obs;
+    sm.time_solve_s = t1 - t0;
+    sm.linear_solver_used = solver;
+    if (user_log && !log.empty()) {
+      const int n = std::min(std::min(sm.num_iterations, user_cap), P.log_cap);
+      memcpy(user_log, log.data() + (size_t)w * P.log_cap, sizeof(hipba_iteration) * n);
+    }
+    if (o.minimizer_progress_to_stdout && !log.empty()) {
+      if (P.n_windows > 1) printf("window %d\n", w);
+      print_progress(log.data() + (size_t)w * P.log_cap, std::min(sm.num_iterations, P.log_cap));
+      static const char* names[] = {"CONVERGENCE", "NO_CONVERGENCE", "FAILURE"};
+      printf("Termination: %s  initial cost %.6e  final cost %.6e  iterations %d  (%.3f ms)\n",
+             names[term < 0 || term > 2 ? 2 : term], sm.initial_cost, sm.final_cost, sm.num_iterations,
+             1e3 * sm.time_solve_s);
+    }
+  }
+  return HIPBA_OK;
+}
+
+// current parameters of every window, into caller arrays (window w: probs[w].poses / points)
+int download_all(hipba_handle_s* h, hipba_device_problem_s* R, hipba_problem* probs, const hipba_summary* summaries) {
+  const DevP& P = R->P;
+  std::vector<WinState> ws(P.n_windows);
+  HIPBA_HIP(hipMemcpy(ws.data(), P.ws, sizeof(WinState) * P.n_windows, hipMemcpyDeviceToHost));
+  std::vector<double> poses[2], points[2];
+  for (int k = 0; k < 2; ++k) {
+    poses[k].resize(std::max<size_t>(7 * (size_t)P.n_poses, 7));
+    points[k].resize(std::max<size_t>(3 * (size_t)P.n_pm_points, 3));
+    if (P.n_poses) HIPBA_HIP(hipMemcpyAsync(poses[k].data(), P.poses[k], sizeof(double) * 7 * P.n_poses, hipMemcpyDeviceToHost, h->stream));
+    if (P.n_pm_points) HIPBA_HIP(hipMemcpyAsync(points[k].data(), P.points[k], sizeof(double) * 3 * P.n_pm_points, hipMemcpyDeviceToHost, h->stream));
+  }
+  HIPBA_HIP(hipStreamSynchronize(h->stream));
+  for (int w = 0; w < P.n_windows; ++w) {
+    if (summaries && summaries[w].termination_type == HIPBA_FAILURE) continue;  // Ceres: solution not usable
+    const int sel = ws[w].sel;
+    const WinMeta& m = R->meta[w];
+    if (m.n_poses) memcpy(probs[w].poses, poses[sel].data() + 7ll * m.pose_base, sizeof(double) * 7 * m.n_poses);
+    for (int i = 0; i < m.n_points; ++i) {
+      const int dp = m.dp_of[i];
+      if (dp < P.n_pm_points) {
+        probs[w].points[3 * i] = points[sel][3ll * dp];
+        probs[w].points[3 * i + 1] = points[sel][3ll * dp + 1];
+        probs[w].points[3 * i + 2] = points[sel][3ll * dp + 2];
+      }
+    }
+  }
+  return HIPBA_OK;
+}
+
+void free_resident(hipba_device_problem_s* R) {
+  if (!R) return;
+  if (R->owns_arena && R->arena) (void)hipFree(R->arena);
+  delete R;
+}
+
+}  // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+int hipba_version(void) { return HIPBA_VERSION; }
+
+const char* hipba_last_error(void) { return g_last_error.c_str(); }
+
+void hipba_options_default(hipba_options* o) {
+  if (!o) return;
+  memset(o, 0, sizeof(*o));
+  o->max_num_iterations = 50;
+  o->loss = HIPBA_LOSS_NONE;
+  o->loss_scale = 1.0;
+  o->linear_solver = HIPBA_LINEAR_AUTO;
+  o->jacobi_scaling = 1;
+  o->initial_trust_region_radius = 1e4;
+  o->max_trust_region_radius = 1e16;
+  o->min_trust_region_radius = 1e-32;
+  o->min_relative_decrease = 1e-3;
+  o->min_lm_diagonal = 1e-6;
+  o->max_lm_diagonal = 1e32;
+  o->max_num_consecutive_invalid_steps = 5;
+  o->function_tolerance = 1e-6;
+  o->gradient_tolerance = 1e-10;
+  o->parameter_tolerance = 1e-8;
+  o->pcg_max_iterations = 500;
+  o->pcg_tolerance = 1e-12;
+  o->minimizer_progress_to_stdout = 0;
+}
+
+int hipba_create(int device, hipba_handle* out) {
+  if (!out) return fail(HIPBA_ERR_INVALID_ARGUMENT, "out is null");
+  *out = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0)
+    return fail(HIPBA_ERR_NO_DEVICE, "no HIP device available (%s); this library has no CPU path",
+                e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+  if (device < 0 || device >= count) return fail(HIPBA_ERR_INVALID_ARGUMENT, "device %d out of range (0..%d)", device, count - 1);
+  HIPBA_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIPBA_HIP(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(HIPBA_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+  auto* h = new hipba_handle_s();
+  h->device = device;
+  e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_count, 64, hipHostMallocDefault);
+  if (e != hipSuccess) { delete h; return fail(HIPBA_ERR_HIP, "handle creation: %s", hipGetErrorString(e)); }
+  *out = h;
+  return HIPBA_OK;
+}
+
+int hipba_destroy(hipba_handle h) {
+  if (!h) return HIPBA_OK;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->arena) (void)hipFree(h->arena);
+  if (h->staging) (void)hipHostFree(h->staging);
+  if (h->h_count) (void)hipHostFree(h->h_count);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return HIPBA_OK;
+}
+
+void* hipba_stream(hipba_handle h) { return h ? (void*)h->stream : nullptr; }
+
+int hipba_solve_batched(hipba_handle h, int32_t n_windows, hipba_problem* problems, const hipba_options* options,
+                        hipba_summary* summaries) {
+  if (!h || !problems || !summaries || n_windows <= 0) return fail(HIPBA_ERR_INVALID_ARGUMENT, "null argument");
+  hipba_options o;
+  if (options) o = *options; else hipba_options_default(&o);
+  HIPBA_HIP(hipSetDevice(h->device));
+  const double t0 = now_s();
+  hipba_device_problem_s* R = nullptr;
+  int rc = build_resident(h, n_windows, problems, true, std::max(o.max_num_iterations, 0) + 1, false, &R);
+  if (rc) return rc;
+  const double t1 = now_s();
+  rc = run_lm(h, R, o, nullptr, summaries);
+  if (!rc) rc = download_all(h, R, problems, summaries);
+  free_resident(R);
+  const double t2 = now_s();
+  if (!rc) {
+    for (int w = 0; w < n_windows; ++w) {
+      summaries[w].time_setup_s = t1 - t0;
+      summaries[w].time_total_s = t2 - t0;
+    }
+  }
+  return rc;
+}
+
+int hipba_solve(hipba_handle h, hipba_problem* problem, const hipba_options* options, hipba_summary* summary) {
+  return hipba_solve_batched(h, 1, problem, options, summary);
+}
+
+int hipba_upload(hipba_handle h, int32_t n_windows, const hipba_problem* problems, hipba_device_problem* out) {
+  if (!h || !problems || !out || n_windows <= 0) return fail(HIPBA_ERR_INVALID_ARGUMENT, "null argument");
+  HIPBA_HIP(hipSetDevice(h->device));
+  hipba_device_problem_s* R = nullptr;
+  // resident problems keep room for Ceres' production iteration budget (optimizer.cpp:58)
+  int rc = build_resident(h, n_windows, problems, false, 301, false, &R);
+  if (rc) return rc;
+  *out = R;
+  return HIPBA_OK;
+}
+
+int hipba_upload_shard(hipba_handle h, const hipba_problem* shard, hipba_device_problem* out) {
+  if (!h || !shard || !out) return fail(HIPBA_ERR_INVALID_ARGUMENT, "null argument");
+  HIPBA_HIP(hipSetDevice(h->device));
+  hipba_device_problem_s* R = nullptr;
+  int rc = build_resident(h, 1, shard, false, 301, true, &R);
+  if (rc) return rc;
+  *out = R;
+  return HIPBA_OK;
+}
+
+int hipba_reset(hipba_handle h, hipba_device_problem dp) {
+  if (!h || !dp) return fail(HIPBA_ERR_INVALID_ARGUMENT, "null argument");
+  HIPBA_HIP(hipSetDevice(h->device));
+  const DevP& P = dp->P;
+  const size_t pb = sizeof(double) * std::max<size_t>(7 * (size_t)P.n_poses, 7);
+  const size_t qb = sizeof(double) * std::max<size_t>(3 * (size_t)P.n_points, 3);
+  for (int k = 0; k < 2; ++k) {
+    HIPBA_HIP(hipMemcpyAsync(P.poses[k], dp->poses0, pb, hipMemcpyDeviceToDevice, h->stream));
+    HIPBA_HIP(hipMemcpyAsync(P.points[k], dp->points0, qb, hipMemcpyDeviceToDevice, h->stream));
+  }
+  HIPBA_HIP(hipMemsetAsync(P.ws, 0, sizeof(WinState) * P.n_windows, h->stream));
+  HIPBA_HIP(hipStreamSynchronize(h->stream));
+  return HIPBA_OK;
+}
+
+int hipba_solve_device(hipba_handle h, hipba_device_problem dp, const hipba_options* options, hipba_summary* summaries) {
+  if (!h || !dp || !summaries) return fail(HIPBA_ERR_INVALID_ARGUMENT, "null argument");
+  hipba_options o;
+  if (options) o = *options; else hipba_options_default(&o);
+  if (o.max_num_iterations + 1 > dp->P.log_cap) {
+    // the log of a resident problem has a fixed capacity; longer runs simply stop logging
+  }
+  HIPBA_HIP(hipSetDevice(h->device));
+  const double t0 = now_s();
+  int rc = run_lm(h, dp, o, nullptr, summaries);
+  if (!rc)
+    for (int w = 0; w < dp->P.n_windows; ++w) { summaries[w].time_setup_s = 0.0; summaries[w].time_total_s = now_s() - t0; }
+  return rc;
+}
+
+int hipba_solve_device_sharded(hipba_handle h, hipba_device_problem dp, const hipba_comm* comm,
+                               const hipba_options* options, hipba_summary* summary) {
+  if (!h || !dp || !summary || !comm) return fail(HIPBA_ERR_INVALID_ARGUMENT, "null argument");
+  hipba_options o;
+  if (options) o = *options; else hipba_options_default(&o);
+  HIPBA_HIP(hipSetDevice(h->device));
+  const double t0 = now_s();
+  int rc = run_lm(h, dp, o, comm, summary);
+  if (!rc) { summary->time_setup_s = 0.0; summary->time_total_s = now_s() - t0; }
+  return rc;
+}
+
+int hipba_download(hipba_handle h, hipba_device_problem dp, int32_t window, double* poses, double* points) {
+  if (!h || !dp) return fail(HIPBA_ERR_INVALID_ARGUMENT, "null argument");
+  if (window < 0 || window >= dp->P.n_windows) return fail(HIPBA_ERR_INVALID_ARGUMENT, "window %d out of range", window);
+  HIPBA_HIP(hipSetDevice(h->device));
+  const DevP& P = dp->P;
+  const WinMeta& m = dp->meta[window];
+  WinState st;
+  HIPBA_HIP(hipMemcpy(&st, P.ws + window, sizeof(WinState), hipMemcpyDeviceToHost));
+  if (poses && m.n_poses)
+    HIPBA_HIP(hipMemcpy(poses, P.poses[st.sel] + 7ll * m.pose_base, sizeof(double) * 7 * m.n_poses, hipMemcpyDeviceToHost));
+  if (points && m.n_points) {
+    std::vector<double> all(3 * (size_t)P.n_points);
+    HIPBA_HIP(hipMemcpy(all.data(), P.points[st.sel], sizeof(double) * all.size(), hipMemcpyDeviceToHost));
+    for (int i = 0; i < m.n_points; ++i) {
+      const int d = m.dp_of[i];
+      points[3 * i] = all[3ll * d]; points[3 * i + 1] = all[3ll * d + 1]; points[3 * i + 2] = all[3ll * d + 2];
+    }
+  }
+  return HIPBA_OK;
+}
+
+int hipba_free_problem(hipba_handle h, hipba_device_problem dp) {
+  if (!dp) return HIPBA_OK;
+  if (h) { (void)hipSetDevice(h->device); (void)hipStreamSynchronize(h->stream); }
+  free_resident(dp);
+  return HIPBA_OK;
+}
+
+int hipba_evaluate(hipba_handle h, const hipba_problem* p, const hipba_options* options, int apply_loss, double* cost,
+                   double* residuals, double* jac_pose, double* jac_point) {
+  if (!h || !p) return fail(HIPBA_ERR_INVALID_ARGUMENT, "null argument");
+  int rc = validate_problem(*p, 0);
+  if (rc) return rc;
+  hipba_options o;
+  if (options) o = *options; else hipba_options_default(&o);
+  HIPBA_HIP(hipSetDevice(h->device));
+  const long long n = p->n_obs;
+  if (n == 0) { if (cost) *cost = 0.0; return HIPBA_OK; }
+  const long long nb = (n + kBlock - 1) / kBlock;
+  ArenaPlan plan;
+  double *d_poses, *d_points, *d_uv, *d_res, *d_jc, *d_jp, *d_part, *d_cost;
+  int *d_op, *d_oq;
+  plan.add(&d_poses, 7 * (size_t)p->n_poses);
+  plan.add(&d_points, 3 * (size_t)p->n_points);
+  plan.add(&d_uv, 2 * (size_t)n);
+  plan.add(&d_op, (size_t)n);
+  plan.add(&d_oq, (size_t)n);
+  plan.add(&d_res, 2 * (size_t)n);
+  plan.add(&d_jc, 12 * (size_t)n);
+  plan.add(&d_jp, 6 * (size_t)n);
+  plan.add(&d_part, (size_t)nb);
+  plan.add(&d_cost, 2);
+  void* base = nullptr;
+  HIPBA_HIP(hipMalloc(&base, plan.total));
+  plan.bind(base);
+  hipStream_t s = h->stream;
+  auto body = [&]() -> int {
+    HIPBA_HIP(hipMemcpyAsync(d_poses, p->poses, sizeof(double) * 7 * p->n_poses, hipMemcpyHostToDevice, s));
+    HIPBA_HIP(hipMemcpyAsync(d_points, p->points, sizeof(double) * 3 * p->n_points, hipMemcpyHostToDevice, s));
+    HIPBA_HIP(hipMemcpyAsync(d_uv, p->obs_uv, sizeof(double) * 2 * n, hipMemcpyHostToDevice, s));
+    HIPBA_HIP(hipMemcpyAsync(d_op, p->obs_pose, sizeof(int) * n, hipMemcpyHostToDevice, s));
+    HIPBA_HIP(hipMemcpyAsync(d_oq, p->obs_point, sizeof(int) * n, hipMemcpyHostToDevice, s));
+    const CameraK K{p->fx, p->fy, p->cx, p->cy, p->camera_model};
+    HIPBA_HIP(launch_residual_jacobian(K, make_lm(o), apply_loss, n, d_poses, d_points, d_op, d_oq, d_uv,
+                                       residuals ? d_res : nullptr, jac_pose ? d_jc : nullptr,
+                                       jac_point ? d_jp : nullptr, d_part, d_cost, s));
+    if (residuals) HIPBA_HIP(hipMemcpyAsync(residuals, d_res, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, s));
+    if (jac_pose) HIPBA_HIP(hipMemcpyAsync(jac_pose, d_jc, sizeof(double) * 12 * n, hipMemcpyDeviceToHost, s));
+    if (jac_point) HIPBA_HIP(hipMemcpyAsync(jac_point, d_jp, sizeof(double) * 6 * n, hipMemcpyDeviceToHost, s));
+    if (cost) HIPBA_HIP(hipMemcpyAsync(cost, d_cost, sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPBA_HIP(hipStreamSynchronize(s));
+    return HIPBA_OK;
+  };
+  rc = body();
+  (void)hipFree(base);
+  return rc;
+}
+
+int hipba_time_kernel(hipba_handle h, hipba_device_problem dp, const hipba_options* options, int32_t kernel,
+                      int32_t repeats, double* avg_ms) {
+  if (!h || !dp || !avg_ms || repeats <= 0) return fail(HIPBA_ERR_INVALID_ARGUMENT, "null argument");
+  hipba_options o;
+  if (options) o = *options; else hipba_options_default(&o);
+  HIPBA_HIP(hipSetDevice(h->device));
+  DevP P = dp->P;
+  hipStream_t s = h->stream;
+  LmParams lm = make_lm(o);
+  if (lm.max_num_iterations < 1) lm.max_num_iterations = 1;
+  const int n_act_blk = P.n_blk_pm + P.n_blk_vc;
+  const int max_n = 6 * dp->max_ncam;
+  const bool small = max_n <= kSmallMaxN;
+  int lds_acc_ncam = (dp->max_ncam > 0 && dp->max_ncam <= 20) ? dp->max_ncam : 0;
+  // bring the work arrays to the state of a first iteration (parameters are not modified)
+  auto prepare = [&]() -> int {
+    HIPBA_HIP(launch_cost(P, lm, 0, n_act_blk, 0, 1, false, s));
+    HIPBA_HIP(launch_cost(P, lm, n_act_blk, P.n_blk_cc, 0, 1, false, s));
+    HIPBA_HIP(launch_window_init(P, lm, kFused, s));
+    HIPBA_HIP(launch_camera_blocks(P, lm, 0, s));
+    HIPBA_HIP(launch_make_scale_c(P, lm.jacobi_scaling, s));
+    HIPBA_HIP(launch_point_colnorm(P, lm, s));
+    if (dp->S_doubles) HIPBA_HIP(hipMemsetAsync(P.S, 0, sizeof(double) * (size_t)dp->S_doubles, s));
+    HIPBA_HIP(launch_init_reduced(P, lm, 1, s));
+    HIPBA_HIP(launch_point_schur(P, lm, lds_acc_ncam, s));
+    return HIPBA_OK;
+  };
+  auto solve_once = [&]() -> int {
+    if (small) HIPBA_HIP(launch_window_solve_small(P, lm, max_n, s));
+    else if (o.linear_solver == HIPBA_LINEAR_PCG) HIPBA_HIP(big_solve_pcg(P, dp->big, o.pcg_max_iterations, o.pcg_tolerance, s));
+    else HIPBA_HIP(big_solve_cholesky(P, dp->big, s));
+    return HIPBA_OK;
+  };
+  int rc = prepare();
+  if (rc) return rc;
+  if (kernel == HIPBA_KERNEL_BACKSUB) { rc = solve_once(); if (rc) return rc; }
+  // the materialising kernel writes 2 + 12 + 6 doubles per observation into a scratch allocation
+  double* jbuf = nullptr;
+  const long long nj = P.n_act_obs;
+  if (kernel == HIPBA_KERNEL_RESIDUAL_JACOBIAN) {
+    if (P.n_windows != 1) return fail(HIPBA_ERR_UNSUPPORTED, "the materialising kernel is timed on single-window problems");
+    HIPBA_HIP(hipMalloc((void**)&jbuf, sizeof(double) * 20 * (size_t)std::max<long long>(nj, 1)));
+  }
+  WinState st0;
+  HIPBA_HIP(hipMemcpy(&st0, P.ws, sizeof(WinState), hipMemcpyDeviceToHost));
+  WinDesc wd0;
+  HIPBA_HIP(hipMemcpy(&wd0, P.wd, sizeof(WinDesc), hipMemcpyDeviceToHost));
+  hipEvent_t e0, e1;
+  HIPBA_HIP(hipEventCreate(&e0));
+  HIPBA_HIP(hipEventCreate(&e1));
+  float total_ms = 0.f;
+  auto one = [&]() -> int {
+    switch (kernel) {
+      case HIPBA_KERNEL_RESIDUAL: HIPBA_HIP(launch_cost(P, lm, 0, n_act_blk, 0, 1, true, s)); break;
+      case HIPBA_KERNEL_RESIDUAL_JACOBIAN:
+        HIPBA_HIP(launch_residual_jacobian(wd0.K, lm, 1, nj, P.poses[st0.sel], P.points[st0.sel], P.obs_pose, P.obs_dp,
+                                           P.obs_uv, jbuf, jbuf + 2 * nj, jbuf + 14 * nj, nullptr, nullptr, s));
+        break;
+      case HIPBA_KERNEL_CAMERA_BLOCKS: HIPBA_HIP(launch_camera_blocks(P, lm, 1, s)); break;
+      case HIPBA_KERNEL_POINT_SCHUR: HIPBA_HIP(launch_point_schur(P, lm, lds_acc_ncam, s)); break;
+      case HIPBA_KERNEL_BACKSUB: HIPBA_HIP(launch_backsub(P, lm, s)); break;
+      case HIPBA_KERNEL_REDUCED_SOLVE: return solve_once();
+      default: return fail(HIPBA_ERR_INVALID_ARGUMENT, "kernel %d cannot be timed on a resident problem", kernel);
+    }
+    return HIPBA_OK;
+  };
+  rc = one();  // warm-up
+  if (!rc) {
+    if (kernel == HIPBA_KERNEL_REDUCED_SOLVE) {
+      // the factorisation destroys nothing it needs again, but the Schur matrix must be rebuilt per repeat
+      for (int i = 0; i < repeats && !rc; ++i) {
+        if (dp->S_doubles) HIPBA_HIP(hipMemsetAsync(P.S, 0, sizeof(double) * (size_t)dp->S_doubles, s));
+        HIPBA_HIP(launch_init_reduced(P, lm, 1, s));
+        HIPBA_HIP(launch_point_schur(P, lm, lds_acc_ncam, s));
+        HIPBA_HIP(hipEventRecord(e0, s));
+        rc = one();
+        HIPBA_HIP(hipEventRecord(e1, s));
+        HIPBA_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIPBA_HIP(hipEventElapsedTime(&ms, e0, e1));
+        total_ms += ms;
+      }
+    } else {
+      HIPBA_HIP(hipEventRecord(e0, s));
+      for (int i = 0; i < repeats && !rc; ++i) rc = one();
+      HIPBA_HIP(hipEventRecord(e1, s));
+      HIPBA_HIP(hipEventSynchronize(e1));
+      HIPBA_HIP(hipEventElapsedTime(&total_ms, e0, e1));
+    }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (jbuf) { (void)hipStreamSynchronize(s); (void)hipFree(jbuf); }
+  if (rc) return rc;
+  *avg_ms = (double)total_ms / repeats;
+  // leave the window state as a finished solve would: nothing active
+  HIPBA_HIP(hipStreamSynchronize(s));
+  return HIPBA_OK;
+}
+
+}  // extern "C"

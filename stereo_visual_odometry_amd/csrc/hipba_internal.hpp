@@ -1,0 +1,52 @@
+// hipba_internal.hpp -- host-side declarations shared by the translation units of libhipba.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "ba_device.hpp"
+
+namespace hipba {
+
+// ---- kernel launch wrappers (lm_kernels.hip) ---------------------------------------------------
+size_t schur_lds_bytes(int max_ncam_lds);
+hipError_t launch_cost(const DevP& P, const LmParams& lm, int blk_off, int n_blk, int which, int ignore_active,
+                       bool second_bank, hipStream_t s);
+hipError_t launch_camera_blocks(const DevP& P, const LmParams& lm, int use_scale, hipStream_t s);
+hipError_t launch_make_scale_c(const DevP& P, int jacobi, hipStream_t s);
+hipError_t launch_point_colnorm(const DevP& P, const LmParams& lm, hipStream_t s);
+hipError_t launch_init_reduced(const DevP& P, const LmParams& lm, int owner, hipStream_t s);
+hipError_t launch_point_schur(const DevP& P, const LmParams& lm, int lds_acc_ncam, hipStream_t s);
+hipError_t launch_window_solve_small(const DevP& P, const LmParams& lm, int max_n, hipStream_t s);
+hipError_t launch_window_gradient(const DevP& P, const LmParams& lm, int mode, hipStream_t s);
+hipError_t launch_backsub(const DevP& P, const LmParams& lm, hipStream_t s);
+hipError_t launch_pose_update(const DevP& P, hipStream_t s);
+hipError_t launch_window_init(const DevP& P, const LmParams& lm, int mode, hipStream_t s);
+hipError_t launch_window_control(const DevP& P, const LmParams& lm, int mode, hipStream_t s);
+hipError_t launch_count_active(const DevP& P, int* out, hipStream_t s);
+hipError_t launch_residual_jacobian(const CameraK& K, const LmParams& lm, int apply_loss, long long n_obs,
+                                    const double* poses, const double* points, const int* obs_pose,
+                                    const int* obs_point, const double* obs_uv, double* res, double* jc, double* jp,
+                                    double* cost_part, double* cost_out, hipStream_t s);
+
+// ---- reduced-system solvers for one large window (dense_solver.hip) ----------------------------
+struct BigWork {
+  int n = 0;           // 6 * ncam
+  int npad = 0;        // n rounded up to the factorisation panel width
+  double* A = nullptr;     // [npad * npad] column-major, lower triangle holds S then its Cholesky factor
+  double* Linv = nullptr;  // [npad/NB][NB*NB] inverses of the diagonal blocks of L
+  double* rhs = nullptr;   // [npad]
+  double* pcg = nullptr;   // PCG vectors and scalars
+  double* Minv = nullptr;  // [36 * ncam] block-Jacobi preconditioner
+  size_t bytes() const;
+};
+constexpr int kCholNB = 128;
+size_t big_work_bytes(int n, int ncam);
+void big_work_bind(BigWork& W, int n, int ncam, void* base);
+// Cholesky: S (packed, P.S) y = b (P.b) -> P.yc; marks ws.solve_failed when S is not positive definite
+hipError_t big_solve_cholesky(const DevP& P, const BigWork& W, hipStream_t s);
+// block-Jacobi preconditioned conjugate gradients on the packed S
+hipError_t big_solve_pcg(const DevP& P, const BigWork& W, int max_iter, double tol, hipStream_t s);
+
+}  // namespace hipba

@@ -1,0 +1,1097 @@
+// lm_kernels.hip -- the Levenberg-Marquardt inner loop as gfx950 kernels (fp64).
+//
+// Replaces what ceres::Solve does per iteration for the reference's problem
+// (src/solve/optimizer.cpp:54-61): residual/Jacobian evaluation, normal-equation
+// assembly, the linear solve's elimination steps, candidate evaluation and the
+// trust-region bookkeeping.  Nothing of J is ever written to HBM: every pass
+// recomputes the 2x6 / 2x3 blocks from the (L2-resident) parameters, so an
+// iteration streams the 24-byte observation records a handful of times instead
+// of writing and re-reading 144 bytes of Jacobian per observation.
+//
+// All kernels are batched over windows: a workgroup belongs to exactly one
+// window and returns at once when that window has terminated.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+
+#include "ba_device.hpp"
+
+namespace hipba {
+
+// ------------------------------------------------------------------------------------------
+// reductions (fixed order => bitwise reproducible sums)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+  return v;
+}
+
+// sums N values over the workgroup; the result is valid in every thread of wave 0
+template <int N>
+__device__ __forceinline__ void block_sum(double (&v)[N], double* lds /* N * (blockDim/64) */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = wave_sum(v[i]);
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) lds[wave * N + i] = v[i];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      double s = 0.0;
+      for (int w = 0; w < nw; ++w) s += lds[w * N + i];
+      v[i] = s;
+    }
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ double block_max(double v, double* lds) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  v = wave_max(v);
+  if (lane == 0) lds[wave] = v;
+  __syncthreads();
+  double m = lds[0];
+  for (int w = 1; w < nw; ++w) m = fmax(m, lds[w]);
+  __syncthreads();
+  return m;
+}
+
+__device__ __forceinline__ void atomic_add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }
+
+// One observation, fully corrected the way Ceres hands it to the linear solver: loss
+// corrector (sqrt(rho1) on residual and Jacobian), then Jacobi column scaling.
+// Returns the cost contribution 1/2 rho(|r|^2).
+template <bool WITH_JP>
+__device__ __forceinline__ double eval_obs(const CameraK& K, const LmParams& lm, const double* pose, const double* p,
+                                           double u, double v, const double* sc /*6 or null*/,
+                                           const double* sp /*3 or null*/, double* r, double* Jc, double* Jp) {
+  double jp_local[6];
+  double* jp = WITH_JP ? Jp : jp_local;
+  residual_jacobian(K, pose, p, u, v, r, Jc, jp);
+  const double s = r[0] * r[0] + r[1] * r[1];
+  double rho0 = s;
+  if (lm.loss == HIPBA_LOSS_HUBER) {
+    double f;
+    huber_correct(lm.loss_scale, s, &rho0, &f);
+    r[0] *= f; r[1] *= f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) Jc[i] *= f;
+    if (WITH_JP) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) jp[i] *= f;
+    }
+  }
+  if (sc) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { Jc[i] *= sc[i]; Jc[6 + i] *= sc[i]; }
+  }
+  if (WITH_JP && sp) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { jp[i] *= sp[i]; jp[3 + i] *= sp[i]; }
+  }
+  return 0.5 * rho0;
+}
+
+// ------------------------------------------------------------------------------------------
+// cost pass: 1/2 sum rho(|r|^2) per block (k_residual)
+//   which = 0: at x, 1: at the candidate.  blk_off selects the block range (active or CC).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_cost(DevP P, LmParams lm, int blk_off, int which, int ignore_active) {
+  __shared__ double red[8];
+  const int b = blockIdx.x + blk_off;
+  const BlockDesc d = P.blocks[b];
+  const WinState* st = P.ws + d.window;
+  if (!ignore_active && !st->active) return;
+  if (which == 1 && st->solve_failed) return;
+  const int sel = st->sel ^ which;
+  const CameraK K = P.wd[d.window].K;
+  double acc[2] = {0.0, 0.0};
+  const int t = threadIdx.x;
+  if (t < d.n_obs) {
+    const long long o = d.obs_begin + t;
+    const double* pose = P.poses[sel] + 7ll * P.obs_pose[o];
+    const double* p = P.points[sel] + 3ll * P.obs_dp[o];
+    const double2 uv = reinterpret_cast<const double2*>(P.obs_uv)[o];
+    double r[2];
+    residual_only(K, pose, p, uv.x, uv.y, r);
+    const double s = r[0] * r[0] + r[1] * r[1];
+    double rho0 = s;
+    if (lm.loss == HIPBA_LOSS_HUBER) {
+      double f;
+      huber_correct(lm.loss_scale, s, &rho0, &f);
+    }
+    acc[0] = 0.5 * rho0;
+    acc[1] = isfinite(rho0) ? 0.0 : 1.0;
+  }
+  block_sum<2>(acc, red);
+  if (t == 0) {
+    P.partial[(long long)b * kPartialStride + 0] = acc[0];
+    P.partial[(long long)b * kPartialStride + 1] = acc[1];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// camera blocks: U_c = sum Jc^T Jc (6x6), g_c = sum Jc^T r over the camera's observations,
+// one workgroup per variable pose, walking its camera-major observation list.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_camera_blocks(DevP P, LmParams lm, int use_scale) {
+  __shared__ double red[27 * 4];
+  const int g = blockIdx.x;
+  const int c = P.slot_pose[g];
+  const int w = P.pose_window[c];
+  const WinState* st = P.ws + w;
+  if (!st->active) return;
+  const int sel = st->sel;
+  const CameraK K = P.wd[w].K;
+  double pose[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) pose[i] = P.poses[sel][7ll * c + i];
+  double sc[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) sc[i] = use_scale ? P.scale_c[6ll * g + i] : 1.0;
+  double acc[27];
+#pragma unroll
+  for (int i = 0; i < 27; ++i) acc[i] = 0.0;
+  const long long o1 = P.cm_start[g + 1];
+  for (long long o = P.cm_start[g] + threadIdx.x; o < o1; o += kBlock) {
+    const double* p = P.points[sel] + 3ll * P.cm_dp[o];
+    const double2 uv = reinterpret_cast<const double2*>(P.cm_uv)[o];
+    double r[2], Jc[12];
+    eval_obs<false>(K, lm, pose, p, uv.x, uv.y, sc, nullptr, r, Jc, nullptr);
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+#pragma unroll
+      for (int j = i; j < 6; ++j) { acc[k] += Jc[i] * Jc[j] + Jc[6 + i] * Jc[6 + j]; ++k; }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) acc[21 + i] += Jc[i] * r[0] + Jc[6 + i] * r[1];
+  }
+  block_sum<27>(acc, red);
+  if (threadIdx.x == 0) {
+    double* U = P.U + 36ll * g;
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+#pragma unroll
+      for (int j = i; j < 6; ++j) { U[6 * i + j] = acc[k]; U[6 * j + i] = acc[k]; ++k; }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) P.gc[6ll * g + i] = acc[21 + i];
+  }
+}
+
+// Jacobi scaling of the pose columns, computed once at iteration 0 from the unscaled blocks
+// (Ceres: scale = 1 / (1 + sqrt(squared column norm))), then folded into U and g.
+__global__ void k_make_scale_c(DevP P, int jacobi) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= P.n_act_poses) return;
+  double* U = P.U + 36ll * g;
+  double s[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    s[i] = jacobi ? 1.0 / (1.0 + sqrt(U[7 * i])) : 1.0;
+    P.scale_c[6ll * g + i] = s[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) U[6 * i + j] *= s[i] * s[j];
+    P.gc[6ll * g + i] *= s[i];
+  }
+}
+
+// Jacobi scaling of the landmark columns (iteration 0): unscaled squared column norms per landmark.
+__global__ __launch_bounds__(kBlock) void k_point_colnorm(DevP P, LmParams lm) {
+  __shared__ double sh[kBlock * 3];
+  const BlockDesc d = P.blocks[blockIdx.x];
+  const WinState* st = P.ws + d.window;
+  if (!st->active) return;
+  const int sel = st->sel;
+  const CameraK K = P.wd[d.window].K;
+  const int t = threadIdx.x;
+  int pp = -1;
+  if (t < d.n_obs) {
+    const long long o = d.obs_begin + t;
+    pp = P.obs_dp[o];
+    const double* pose = P.poses[sel] + 7ll * P.obs_pose[o];
+    const double* p = P.points[sel] + 3ll * pp;
+    const double2 uv = reinterpret_cast<const double2*>(P.obs_uv)[o];
+    double r[2], Jc[12], Jp[6];
+    eval_obs<true>(K, lm, pose, p, uv.x, uv.y, nullptr, nullptr, r, Jc, Jp);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) sh[3 * t + i] = Jp[i] * Jp[i] + Jp[3 + i] * Jp[3 + i];
+  }
+  __syncthreads();
+  if (t < d.n_obs) {
+    const int s0 = (int)(P.pp_obs_start[pp] - d.obs_begin);
+    if (t == s0) {
+      const int s1 = (int)(P.pp_obs_start[pp + 1] - d.obs_begin);
+      double n[3] = {0.0, 0.0, 0.0};
+      for (int j = s0; j < s1; ++j) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) n[i] += sh[3 * j + i];
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) P.scale_p[3ll * pp + i] = lm.jacobi_scaling ? 1.0 / (1.0 + sqrt(n[i])) : 1.0;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// reduced system initialisation, one thread per variable pose:
+//   S(c,c) = U_c + D_c^2,  b_c = g_c,  and the pose part of |x - Plus(x, -g)|.
+// S must have been zeroed on the stream before this kernel.
+// ------------------------------------------------------------------------------------------
+__global__ void k_init_reduced(DevP P, LmParams lm, int owner) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= P.n_act_poses) return;
+  const int c = P.slot_pose[g];
+  const int w = P.pose_window[c];
+  WinState* st = P.ws + w;
+  if (!st->active) return;
+  const WinDesc wd = P.wd[w];
+  const int slot = g - wd.cam_base;
+  double* Sb = P.S + wd.S_off + 36ll * tri_index(slot, slot, wd.ncam);
+  const double* U = P.U + 36ll * g;
+  const double inv_radius = 1.0 / st->radius;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      double v = U[6 * i + j];
+      if (i == j) {
+        double dg = fmin(fmax(v, lm.min_lm_diagonal), lm.max_lm_diagonal);
+        v += dg * inv_radius;
+      }
+      if (owner) Sb[6 * i + j] = v;  // sharded solves: one rank contributes U + D^2 and g_c
+    }
+  }
+  double neg[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const double gs = P.gc[6ll * g + i];
+    P.b[6ll * g + i] = owner ? gs : 0.0;
+    neg[i] = -gs / P.scale_c[6ll * g + i];
+  }
+  // gradient norms are defined through the retraction: |x - Plus(x, -g)|
+  const double* x = P.poses[st->sel] + 7ll * c;
+  double xp[7], xx[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) xx[i] = x[i];
+  se3_plus(xx, neg, xp);
+  double m = 0.0, s2 = 0.0;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const double dlt = xx[i] - xp[i];
+    m = fmax(m, fabs(dlt));
+    s2 += dlt * dlt;
+  }
+  // stash per pose in yc (overwritten by the solver afterwards): [0]=max, [1]=sum of squares
+  P.yc[6ll * g + 0] = m;
+  P.yc[6ll * g + 1] = s2;
+}
+
+// ------------------------------------------------------------------------------------------
+// landmark elimination (k_schur_point + k_schur_camera of the design):
+// per landmark V = sum Jp^T Jp + D^2 (3x3), g_p, V^-1; per observation W = Jc^T Jp (6x3),
+// Y = W V^-1; reduced system S(ci,cj) -= Y_i W_j^T, b(ci) -= Y_i g_p.
+//
+// Phase 1: one lane per observation evaluates r, Jc, Jp and stages its V/g_p contribution
+//          in LDS.  Phase 2: every lane of a landmark's segment sums the segment (the same
+//          LDS words are broadcast to all of them), inverts V and stages W, Y.  Phase 3:
+//          groups of 12 lanes walk the block's precomputed pair list; a group owns one 6x6
+//          block at a time and its three atomic wave-instructions each cover 96 contiguous
+//          bytes of that block (S is stored block-major for exactly this reason).
+// LDS_ACC: the window's whole packed S and b fit in LDS; accumulate there and flush once.
+// ------------------------------------------------------------------------------------------
+constexpr int kPairGroup = 12;
+constexpr int kPairGroups = kBlock / kPairGroup;  // 21
+
+template <bool LDS_ACC>
+__global__ __launch_bounds__(kBlock) void k_point_schur(DevP P, LmParams lm) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* sYW = smem;                         // [kBlock][36]: Y (18) then W (18); phase 1 aliases 9 words/lane
+  int* sslot = reinterpret_cast<int*>(smem + kBlock * 36);  // [kBlock] local slot or -1
+  double* red = smem + kBlock * 36 + kBlock / 2;             // [8]
+  double* accS = red + 8;                                      // LDS_ACC: packed S then b
+
+  const BlockDesc d = P.blocks[blockIdx.x];
+  const int w = d.window;
+  const WinState* st = P.ws + w;
+  if (!st->active) return;
+  const WinDesc wd = P.wd[w];
+  const int sel = st->sel;
+  const double inv_radius = 1.0 / st->radius;
+  const int t = threadIdx.x;
+  const int nS = LDS_ACC ? (wd.ncam * (wd.ncam + 1) / 2) * 36 : 0;
+  if (LDS_ACC) {
+    for (int i = t; i < nS + 6 * wd.ncam; i += kBlock) accS[i] = 0.0;
+  }
+
+  double r[2], Jc[12], Jp[6];
+  int pp = -1, slot = -1;
+  const bool live = t < d.n_obs;
+  if (live) {
+    const long long o = d.obs_begin + t;
+    pp = P.obs_dp[o];
+    const int c = P.obs_pose[o];
+    const int g = P.pose_gslot[c];
+    slot = g < 0 ? -1 : g - wd.cam_base;
+    const double* pose = P.poses[sel] + 7ll * c;
+    const double* p = P.points[sel] + 3ll * pp;
+    const double2 uv = reinterpret_cast<const double2*>(P.obs_uv)[o];
+    eval_obs<true>(wd.K, lm, pose, p, uv.x, uv.y, g < 0 ? nullptr : P.scale_c + 6ll * g, P.scale_p + 3ll * pp, r, Jc,
+                   Jp);
+    double* cw = sYW + 9 * t;
+    cw[0] = Jp[0] * Jp[0] + Jp[3] * Jp[3];
+    cw[1] = Jp[0] * Jp[1] + Jp[3] * Jp[4];
+    cw[2] = Jp[0] * Jp[2] + Jp[3] * Jp[5];
+    cw[3] = Jp[1] * Jp[1] + Jp[4] * Jp[4];
+    cw[4] = Jp[1] * Jp[2] + Jp[4] * Jp[5];
+    cw[5] = Jp[2] * Jp[2] + Jp[5] * Jp[5];
+    cw[6] = Jp[0] * r[0] + Jp[3] * r[1];
+    cw[7] = Jp[1] * r[0] + Jp[4] * r[1];
+    cw[8] = Jp[2] * r[0] + Jp[5] * r[1];
+  }
+  __syncthreads();
+
+  double Y[18], W[18];
+  double gmax = 0.0, g2 = 0.0;
+  if (live) {
+    const int s0 = (int)(P.pp_obs_start[pp] - d.obs_begin);
+    const int s1 = (int)(P.pp_obs_start[pp + 1] - d.obs_begin);
+    double V[6] = {0, 0, 0, 0, 0, 0}, gpv[3] = {0, 0, 0};
+    for (int j = s0; j < s1; ++j) {
+      const double* cw = sYW + 9 * j;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) V[i] += cw[i];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) gpv[i] += cw[6 + i];
+    }
+    // Levenberg-Marquardt diagonal: clamp(column norm^2) / radius
+    V[0] += fmin(fmax(V[0], lm.min_lm_diagonal), lm.max_lm_diagonal) * inv_radius;
+    V[3] += fmin(fmax(V[3], lm.min_lm_diagonal), lm.max_lm_diagonal) * inv_radius;
+    V[5] += fmin(fmax(V[5], lm.min_lm_diagonal), lm.max_lm_diagonal) * inv_radius;
+    double Vi[6];
+    inv3_sym(V, Vi);
+    if (t == s0) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) P.Vinv[6ll * pp + i] = Vi[i];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        P.gp[3ll * pp + i] = gpv[i];
+        const double gu = gpv[i] / P.scale_p[3ll * pp + i];
+        gmax = fmax(gmax, fabs(gu));
+        g2 += gu * gu;
+      }
+    }
+    if (slot >= 0) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) W[3 * i + j] = Jc[i] * Jp[j] + Jc[6 + i] * Jp[3 + j];
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        Y[3 * i + 0] = W[3 * i] * Vi[0] + W[3 * i + 1] * Vi[1] + W[3 * i + 2] * Vi[2];
+        Y[3 * i + 1] = W[3 * i] * Vi[1] + W[3 * i + 1] * Vi[3] + W[3 * i + 2] * Vi[4];
+        Y[3 * i + 2] = W[3 * i] * Vi[2] + W[3 * i + 1] * Vi[4] + W[3 * i + 2] * Vi[5];
+      }
+      // b_c -= Y g_p
+      double* bdst = LDS_ACC ? accS + nS + 6 * slot : P.b + 6ll * (wd.cam_base + slot);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const double v = Y[3 * i] * gpv[0] + Y[3 * i + 1] * gpv[1] + Y[3 * i + 2] * gpv[2];
+        atomic_add_f64(bdst + i, -v);
+      }
+    }
+  }
+  __syncthreads();  // every lane has finished reading the phase-1 words
+  if (live) {
+    sslot[t] = slot;
+    if (slot >= 0) {
+      double* yw = sYW + 36 * t;
+#pragma unroll
+      for (int i = 0; i < 18; ++i) { yw[i] = Y[i]; yw[18 + i] = W[i]; }
+    }
+  }
+  __syncthreads();
+
+  // phase 3: pair products
+  const int grp = t / kPairGroup, k = t - grp * kPairGroup;
+  if (grp < kPairGroups) {
+    const int bcol = k % 6, a0 = k / 6;
+    for (int q = grp; q < d.n_pairs; q += kPairGroups) {
+      const unsigned short pr = P.pairs[d.pair_begin + q];
+      const int i = pr & 0xff, j = pr >> 8;
+      const int si = sslot[i], sj = sslot[j];
+      const double* Yi = sYW + 36 * i;
+      const double* Wj = sYW + 36 * j + 18 + 3 * bcol;
+      const double w0 = Wj[0], w1 = Wj[1], w2 = Wj[2];
+      double* dst = (LDS_ACC ? accS : P.S + wd.S_off) + 36ll * tri_index(si, sj, wd.ncam);
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        const int a = a0 + 2 * m;
+        const double v = Yi[3 * a] * w0 + Yi[3 * a + 1] * w1 + Yi[3 * a + 2] * w2;
+        atomic_add_f64(dst + 6 * a + bcol, -v);
+      }
+    }
+  }
+
+  // landmark part of the gradient norms
+  gmax = block_max(gmax, red);
+  double gs[1] = {g2};
+  block_sum<1>(gs, red);
+  if (t == 0) {
+    P.gpart[2ll * blockIdx.x + 0] = gmax;
+    P.gpart[2ll * blockIdx.x + 1] = gs[0];
+  }
+  if (LDS_ACC) {
+    __syncthreads();
+    double* Sg = P.S + wd.S_off;
+    for (int i = t; i < nS; i += kBlock) {
+      const double v = accS[i];
+      if (v != 0.0) atomic_add_f64(Sg + i, v);
+    }
+    double* bg = P.b + 6ll * wd.cam_base;
+    for (int i = t; i < 6 * wd.ncam; i += kBlock) {
+      const double v = accS[nS + i];
+      if (v != 0.0) atomic_add_f64(bg + i, v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// back-substitution + model cost change + candidate landmarks, all active blocks:
+//   y_p = V^-1 (g_p - sum W^T y_c),  step = -y,  delta = step * scale,
+//   model_cost_change = -sum m (r + m/2),  m = Jc step_c + Jp step_p   (Ceres'
+//   TrustRegionMinimizer::ComputeTrustRegionStep on the scaled Jacobian).
+// partial[b] = { sum m (r + m/2), |delta_p|^2, |x_p|^2 }
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_backsub(DevP P, LmParams lm) {
+  __shared__ double sh[kBlock * 3];
+  __shared__ double red[3 * 4];
+  const int b = blockIdx.x;
+  const BlockDesc d = P.blocks[b];
+  const int w = d.window;
+  const WinState* st = P.ws + w;
+  if (!st->active || st->solve_failed) return;
+  const WinDesc wd = P.wd[w];
+  const int sel = st->sel;
+  const int t = threadIdx.x;
+  const bool live = t < d.n_obs;
+  double r[2] = {0, 0}, Jc[12], Jp[6];
+  double mc[2] = {0, 0};  // Jc * step_c
+  int pp = -1;
+  bool has_c = false;
+  if (live) {
+    const long long o = d.obs_begin + t;
+    pp = P.obs_dp[o];
+    const int c = P.obs_pose[o];
+    const int g = P.pose_gslot[c];
+    has_c = g >= 0;
+    const double* pose = P.poses[sel] + 7ll * c;
+    const double* p = P.points[sel] + 3ll * pp;
+    const double2 uv = reinterpret_cast<const double2*>(P.obs_uv)[o];
+    const bool pm = d.kind == 0;
+    eval_obs<true>(wd.K, lm, pose, p, uv.x, uv.y, has_c ? P.scale_c + 6ll * g : nullptr,
+                   pm ? P.scale_p + 3ll * pp : nullptr, r, Jc, Jp);
+    if (has_c) {
+      const double* y = P.yc + 6ll * g;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) { mc[0] -= Jc[i] * y[i]; mc[1] -= Jc[6 + i] * y[i]; }
+    }
+  }
+  double acc[3] = {0.0, 0.0, 0.0};
+  if (d.kind == 0) {
+    if (live) {
+      // W^T y_c = Jp^T (Jc y_c) = -Jp^T mc
+#pragma unroll
+      for (int i = 0; i < 3; ++i) sh[3 * t + i] = -(Jp[i] * mc[0] + Jp[3 + i] * mc[1]);
+    }
+    __syncthreads();
+    if (live) {
+      const int s0 = (int)(P.pp_obs_start[pp] - d.obs_begin);
+      const int s1 = (int)(P.pp_obs_start[pp + 1] - d.obs_begin);
+      double tt[3] = {P.gp[3ll * pp], P.gp[3ll * pp + 1], P.gp[3ll * pp + 2]};
+      for (int j = s0; j < s1; ++j) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) tt[i] -= sh[3 * j + i];
+      }
+      const double* Vi = P.Vinv + 6ll * pp;
+      double sp[3];  // step_p = -y_p
+      sp[0] = -(Vi[0] * tt[0] + Vi[1] * tt[1] + Vi[2] * tt[2]);
+      sp[1] = -(Vi[1] * tt[0] + Vi[3] * tt[1] + Vi[4] * tt[2]);
+      sp[2] = -(Vi[2] * tt[0] + Vi[4] * tt[1] + Vi[5] * tt[2]);
+      const double m0 = mc[0] + Jp[0] * sp[0] + Jp[1] * sp[1] + Jp[2] * sp[2];
+      const double m1 = mc[1] + Jp[3] * sp[0] + Jp[4] * sp[1] + Jp[5] * sp[2];
+      acc[0] = m0 * (r[0] + m0 / 2.0) + m1 * (r[1] + m1 / 2.0);
+      if (t == s0) {
+        const double* x = P.points[sel] + 3ll * pp;
+        double* xc = P.points[sel ^ 1] + 3ll * pp;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const double dl = sp[i] * P.scale_p[3ll * pp + i];
+          const double xn = x[i] + dl;
+          xc[i] = xn;
+          const double df = x[i] - xn;
+          acc[1] += df * df;
+          acc[2] += x[i] * x[i];
+        }
+      }
+    }
+  } else if (live) {
+    acc[0] = mc[0] * (r[0] + mc[0] / 2.0) + mc[1] * (r[1] + mc[1] / 2.0);
+  }
+  block_sum<3>(acc, red);
+  if (t == 0) {
+    double* pr = P.partial + (long long)b * kPartialStride;
+    pr[0] = acc[0]; pr[1] = acc[1]; pr[2] = acc[2];
+  }
+}
+
+// candidate poses T * exp(delta_c) (Sophus::Manifold<SE3>::Plus) and their norm terms,
+// one workgroup per window
+__global__ __launch_bounds__(kBlock) void k_pose_update(DevP P) {
+  __shared__ double red[2 * 4];
+  const int w = blockIdx.x;
+  WinState* st = P.ws + w;
+  if (!st->active || st->solve_failed) return;
+  const WinDesc wd = P.wd[w];
+  const int sel = st->sel;
+  double acc[2] = {0.0, 0.0};
+  for (int c = wd.pose_begin + threadIdx.x; c < wd.pose_end; c += kBlock) {
+    const int g = P.pose_gslot[c];
+    if (g < 0) continue;
+    double x[7], dl[6], xn[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) x[i] = P.poses[sel][7ll * c + i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dl[i] = -P.yc[6ll * g + i] * P.scale_c[6ll * g + i];
+    se3_plus(x, dl, xn);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      P.poses[sel ^ 1][7ll * c + i] = xn[i];
+      const double df = x[i] - xn[i];
+      acc[0] += df * df;
+      acc[1] += x[i] * x[i];
+    }
+  }
+  block_sum<2>(acc, red);
+  if (threadIdx.x == 0) { st->pose_step2 = acc[0]; st->pose_x2 = acc[1]; }
+}
+
+// ------------------------------------------------------------------------------------------
+// per-window reductions + the trust-region controller (one workgroup per window)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void log_iteration(const DevP& P, const WinDesc& wd, const hipba_iteration& it) {
+  if (P.log && it.iteration < P.log_cap) P.log[wd.log_base + it.iteration] = it;
+}
+
+// Per-window sums can be completed across ranks (observation-sharded solves): every
+// window kernel below runs in one of three modes
+//   kFused   reduce the per-block partials and decide, in one launch (single GPU)
+//   kReduce  reduce only, leaving the local sums in P.wsum for the caller's all-reduce
+//   kDecide  decide from the (summed) values in P.wsum
+constexpr int kWsum = 8;  // doubles of P.wsum per window
+
+// iteration 0: initial cost, fixed cost, state reset
+__global__ __launch_bounds__(kBlock) void k_window_init(DevP P, LmParams lm, int mode) {
+  __shared__ double red[3 * 4];
+  const int w = blockIdx.x;
+  const WinDesc wd = P.wd[w];
+  WinState* st = P.ws + w;
+  double acc[3] = {0.0, 0.0, 0.0};
+  if (mode != kDecide) {
+    for (int b = wd.pm_blk_begin + threadIdx.x; b < wd.pm_blk_end; b += kBlock) {
+      acc[0] += P.partial[(long long)b * kPartialStride];
+      acc[2] += P.partial[(long long)b * kPartialStride + 1];
+    }
+    for (int b = wd.vc_blk_begin + threadIdx.x; b < wd.vc_blk_end; b += kBlock) {
+      acc[0] += P.partial[(long long)b * kPartialStride];
+      acc[2] += P.partial[(long long)b * kPartialStride + 1];
+    }
+    for (int b = wd.cc_blk_begin + threadIdx.x; b < wd.cc_blk_end; b += kBlock) {
+      acc[1] += P.partial[(long long)b * kPartialStride];
+    }
+    block_sum<3>(acc, red);
+  }
+  if (threadIdx.x != 0) return;
+  if (mode == kReduce) {
+    for (int i = 0; i < 3; ++i) P.wsum[kWsum * w + i] = acc[i];
+    return;
+  }
+  if (mode == kDecide) {
+    for (int i = 0; i < 3; ++i) acc[i] = P.wsum[kWsum * w + i];
+  }
+  const int sel = st->sel;
+  WinState s;
+  s.sel = sel;
+  s.termination = HIPBA_NO_CONVERGENCE;
+  s.iteration = 0;
+  s.n_invalid = 0;
+  s.any_success = 0;
+  s.num_successful = 1;  // Ceres counts iteration 0 as a successful step
+  s.num_unsuccessful = 0;
+  s.solve_failed = 0;
+  s.last_success_log = 0;
+  s.lin_iters = 0;
+  s.pad = 0;
+  s.radius = lm.initial_radius;
+  s.decrease_factor = 2.0;
+  s.x_cost = acc[0];
+  s.fixed_cost = acc[1];
+  s.initial_cost = acc[0] + acc[1];
+  s.gmax = 0.0; s.gnorm = 0.0;
+  s.pose_step2 = s.pose_x2 = s.pose_gmax = s.pose_g2 = 0.0;
+  s.active = 1;
+  const bool nothing = (wd.ncam == 0) && (wd.pp_end == wd.pp_begin) && !P.sharded;
+  if (nothing) { s.active = 0; s.termination = HIPBA_CONVERGENCE; }
+  if (acc[2] > 0.0 || !isfinite(acc[0])) { s.active = 0; s.termination = HIPBA_FAILURE; }
+  hipba_iteration it;
+  it.iteration = 0; it.step_is_valid = 1; it.step_is_successful = 1; it.linear_solver_iterations = 0;
+  it.cost = s.initial_cost; it.cost_change = 0.0; it.gradient_max_norm = 0.0; it.gradient_norm = 0.0;
+  it.step_norm = 0.0; it.relative_decrease = 0.0; it.trust_region_radius = s.radius;
+  log_iteration(P, wd, it);
+  if (s.active && lm.max_num_iterations <= 0) { s.active = 0; s.termination = HIPBA_NO_CONVERGENCE; }
+  *st = s;
+}
+
+// gradient norms of the fresh linearisation + gradient-tolerance test (Ceres checks it when an
+// iteration that moved x is finalised; the norms only exist once the blocks have been rebuilt).
+// wsum slots: [0] landmark max (max-reduced across ranks), [1] landmark sum of squares.
+__device__ void window_gradient_check(const DevP& P, const LmParams& lm, const WinDesc& wd, WinState* st, double* red,
+                                      int mode) {
+  const int w = (int)(st - P.ws);
+  double gm = 0.0;
+  double g2[1] = {0.0};
+  if (mode != kDecide) {
+    for (int b = wd.pm_blk_begin + threadIdx.x; b < wd.pm_blk_end; b += kBlock) {
+      gm = fmax(gm, P.gpart[2ll * b]);
+      g2[0] += P.gpart[2ll * b + 1];
+    }
+    gm = block_max(gm, red);
+    block_sum<1>(g2, red);
+    if (mode == kReduce) {
+      if (threadIdx.x == 0) { P.wsum[kWsum * w] = gm; P.wsum[kWsum * w + 1] = g2[0]; }
+      return;
+    }
+  }
+  double pm = 0.0;
+  double p2[1] = {0.0};
+  for (int g = wd.cam_base + threadIdx.x; g < wd.cam_base + wd.ncam; g += kBlock) {
+    pm = fmax(pm, P.yc[6ll * g]);
+    p2[0] += P.yc[6ll * g + 1];
+  }
+  pm = block_max(pm, red);
+  block_sum<1>(p2, red);
+  if (threadIdx.x == 0) {
+    if (mode == kDecide) { gm = P.wsum[kWsum * w]; g2[0] = P.wsum[kWsum * w + 1]; }
+    gm = fmax(gm, pm);
+    st->gmax = gm;
+    st->gnorm = sqrt(g2[0] + p2[0]);
+    if (P.log && st->last_success_log >= 0 && st->last_success_log < P.log_cap) {
+      hipba_iteration* e = P.log + wd.log_base + st->last_success_log;
+      e->gradient_max_norm = gm;
+      e->gradient_norm = st->gnorm;
+    }
+    if (st->last_success_log == st->iteration && gm <= lm.gradient_tolerance) {
+      st->active = 0;
+      st->termination = HIPBA_CONVERGENCE;
+    }
+  }
+  __syncthreads();
+}
+
+// end of an iteration: reduce the per-block partials and run Ceres' acceptance logic
+// (TrustRegionMinimizer::Minimize, LevenbergMarquardtStrategy::StepAccepted/Rejected/IsInvalid)
+__global__ __launch_bounds__(kBlock) void k_window_control(DevP P, LmParams lm, int mode) {
+  __shared__ double red[5 * 4];
+  const int w = blockIdx.x;
+  WinState* st = P.ws + w;
+  if (!st->active) return;
+  const WinDesc wd = P.wd[w];
+  const bool failed = st->solve_failed != 0;
+  // acc: 0 model term, 1 point step^2, 2 point x^2, 3 candidate cost, 4 bad flag
+  double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  // k_backsub writes the first bank of P.partial, the candidate cost pass the second
+  if (!failed && mode != kDecide) {
+    const long long nb = (long long)P.n_blk_pm + P.n_blk_vc + P.n_blk_cc;
+    const double* p2 = P.partial + nb * kPartialStride;  // second bank: candidate cost
+    for (int b = wd.pm_blk_begin + threadIdx.x; b < wd.pm_blk_end; b += kBlock) {
+      const double* pr = P.partial + (long long)b * kPartialStride;
+      acc[0] += pr[0]; acc[1] += pr[1]; acc[2] += pr[2];
+      acc[3] += p2[(long long)b * kPartialStride]; acc[4] += p2[(long long)b * kPartialStride + 1];
+    }
+    for (int b = wd.vc_blk_begin + threadIdx.x; b < wd.vc_blk_end; b += kBlock) {
+      const double* pr = P.partial + (long long)b * kPartialStride;
+      acc[0] += pr[0];
+      acc[3] += p2[(long long)b * kPartialStride]; acc[4] += p2[(long long)b * kPartialStride + 1];
+    }
+  }
+  if (mode != kDecide) block_sum<5>(acc, red);
+  if (threadIdx.x != 0) return;
+  if (mode == kReduce) {
+    for (int i = 0; i < 5; ++i) P.wsum[kWsum * w + i] = acc[i];
+    return;
+  }
+  if (mode == kDecide) {
+    for (int i = 0; i < 5; ++i) acc[i] = P.wsum[kWsum * w + i];
+  }
+
+  WinState s = *st;
+  const int iter = s.iteration + 1;
+  hipba_iteration it;
+  it.iteration = iter; it.linear_solver_iterations = s.lin_iters;
+  it.gradient_max_norm = s.gmax; it.gradient_norm = s.gnorm;
+  const double model_cost_change = -acc[0];
+  const bool valid = !failed && (model_cost_change > 0.0);
+  bool logged = true;
+  if (!valid) {
+    // HandleInvalidStep
+    s.n_invalid++;
+    if (s.n_invalid >= lm.max_invalid) {
+      s.active = 0; s.termination = HIPBA_FAILURE;
+      *st = s;
+      return;
+    }
+    s.radius *= 0.5;
+    it.step_is_valid = 0; it.step_is_successful = 0;
+    it.cost = s.x_cost + s.fixed_cost; it.cost_change = 0.0; it.step_norm = 0.0; it.relative_decrease = 0.0;
+    s.num_unsuccessful++;
+  } else {
+    s.n_invalid = 0;
+    it.step_is_valid = 1;
+    const double step_norm = sqrt(acc[1] + s.pose_step2);
+    const double x_norm = sqrt(acc[2] + s.pose_x2);
+    it.step_norm = step_norm;
+    double cand = acc[3];
+    if (acc[4] > 0.0 || !isfinite(cand)) cand = DBL_MAX;
+    // ParameterToleranceReached (only after one successful step, as Ceres >= 2.2)
+    if (s.any_success && step_norm <= lm.parameter_tolerance * (x_norm + lm.parameter_tolerance)) {
+      s.active = 0; s.termination = HIPBA_CONVERGENCE;
+      *st = s;
+      return;
+    }
+    // FunctionToleranceReached
+    it.cost_change = s.x_cost - cand;
+    if (fabs(it.cost_change) <= lm.function_tolerance * s.x_cost) {
+      s.active = 0; s.termination = HIPBA_CONVERGENCE;
+      *st = s;
+      return;
+    }
+    it.relative_decrease = (cand >= DBL_MAX) ? -DBL_MAX : it.cost_change / model_cost_change;
+    if (it.relative_decrease > lm.min_relative_decrease) {
+      // HandleSuccessfulStep + StepAccepted
+      s.sel ^= 1;
+      s.x_cost = cand;
+      s.any_success = 1;
+      const double q = 2.0 * it.relative_decrease - 1.0;
+      s.radius = s.radius / fmax(1.0 / 3.0, 1.0 - q * q * q);
+      s.radius = fmin(lm.max_radius, s.radius);
+      s.decrease_factor = 2.0;
+      it.step_is_successful = 1;
+      it.cost = s.x_cost + s.fixed_cost;
+      s.num_successful++;
+      s.last_success_log = iter;
+    } else {
+      // StepRejected
+      s.radius = s.radius / s.decrease_factor;
+      s.decrease_factor *= 2.0;
+      it.step_is_successful = 0;
+      it.cost = cand + s.fixed_cost;
+      s.num_unsuccessful++;
+    }
+  }
+  it.trust_region_radius = s.radius;
+  if (logged) log_iteration(P, wd, it);
+  s.iteration = iter;
+  s.solve_failed = 0;
+  // FinalizeIterationAndCheckIfMinimizerCanContinue (the gradient test runs with the next linearisation)
+  if (iter >= lm.max_num_iterations) { s.active = 0; s.termination = HIPBA_NO_CONVERGENCE; }
+  else if (s.radius <= lm.min_radius) { s.active = 0; s.termination = HIPBA_CONVERGENCE; }
+  *st = s;
+}
+
+// ------------------------------------------------------------------------------------------
+// reduced solve for small windows: gradient check, then Cholesky of the packed S in LDS
+// (one workgroup per window, n = 6 * ncam <= kSmallMaxN)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lidx(int i, int k) { return i * (i + 1) / 2 + k; }  // packed lower, k <= i
+
+__global__ __launch_bounds__(kBlock) void k_window_solve_small(DevP P, LmParams lm) {
+  // all LDS comes from the dynamic region so that its base stays 16-byte aligned
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* red = smem;                                  // [8]
+  int& fail = *reinterpret_cast<int*>(smem + 8);
+  const int w = blockIdx.x;
+  WinState* st = P.ws + w;
+  if (!st->active) return;
+  const WinDesc wd = P.wd[w];
+  window_gradient_check(P, lm, wd, st, red, kFused);
+  if (!st->active) return;
+  const int n = 6 * wd.ncam;
+  if (n == 0) return;
+  // augmented packed lower matrix: rows 0..n-1 = S, row n = b^T (its Cholesky row is L^-1 b)
+  double* A = smem + 10;
+  const int t = threadIdx.x;
+  const int nblk = wd.ncam * (wd.ncam + 1) / 2;
+  const double* Sg = P.S + wd.S_off;
+  // block (bi,bj), bi<=bj, entry (a,c) = S[6bi+a][6bj+c] -> lower element (6bj+c, 6bi+a)
+  for (int e = t; e < nblk * 36; e += kBlock) {
+    const int blk = e / 36, ac = e - blk * 36;
+    const int a = ac / 6, c = ac - a * 6;
+    // decode blk -> (bi,bj)
+    int bi = 0, rem = blk;
+    while (rem >= wd.ncam - bi) { rem -= wd.ncam - bi; ++bi; }
+    const int bj = bi + rem;
+    const int row = 6 * bj + c, col = 6 * bi + a;
+    if (row >= col) A[lidx(row, col)] = Sg[e];
+  }
+  for (int i = t; i < n; i += kBlock) A[lidx(n, i)] = P.b[6ll * wd.cam_base + i];
+  if (t == 0) fail = 0;
+  __syncthreads();
+  const int ti = t & 15, tk = t >> 4;
+  for (int j = 0; j < n; ++j) {
+    const double djj = A[lidx(j, j)];
+    if (!(djj > 0.0) || !isfinite(djj)) {
+      if (t == 0) fail = 1;
+      break;  // uniform: every thread reads the same word
+    }
+    const double inv = 1.0 / sqrt(djj);
+    __syncthreads();
+    for (int i = j + t; i <= n; i += kBlock) A[lidx(i, j)] *= inv;  // includes (j,j) -> sqrt, and row n
+    __syncthreads();
+    // trailing update of rows j+1..n (row n carries the right-hand side)
+    for (int i = j + 1 + ti; i <= n; i += 16) {
+      const double lij = A[lidx(i, j)];
+      const int kend = i < n ? i : n - 1;
+      for (int k = j + 1 + tk; k <= kend; k += 16) A[lidx(i, k)] -= lij * A[lidx(k, j)];
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  if (fail) {
+    if (t == 0) st->solve_failed = 1;
+    return;
+  }
+  // backward substitution L^T y = z by one wave: lane l owns rows l, l+64, l+128
+  if (t < 64) {
+    double z[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) { const int i = t + 64 * m; z[m] = i < n ? A[lidx(n, i)] : 0.0; }
+    for (int j = n - 1; j >= 0; --j) {
+      const int owner = j & 63, m = j >> 6;
+      double zj = (m == 0 ? z[0] : (m == 1 ? z[1] : z[2])) / A[lidx(j, j)];
+      zj = __shfl(zj, owner);
+      if (t == owner) { if (m == 0) z[0] = zj; else if (m == 1) z[1] = zj; else z[2] = zj; }
+#pragma unroll
+      for (int mm = 0; mm < 3; ++mm) {
+        const int i = t + 64 * mm;
+        if (i < j) z[mm] -= A[lidx(j, i)] * zj;
+      }
+    }
+    bool ok = true;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      const int i = t + 64 * m;
+      if (i < n) { P.yc[6ll * wd.cam_base + i] = z[m]; ok = ok && isfinite(z[m]); }
+    }
+    const unsigned long long okm = __ballot(ok);
+    if (t == 0 && okm != ~0ull) st->solve_failed = 1;
+  }
+}
+
+// gradient check alone, for windows whose reduced system is solved by the large-matrix path
+__global__ __launch_bounds__(kBlock) void k_window_gradient(DevP P, LmParams lm, int mode) {
+  __shared__ double red[8];
+  const int w = blockIdx.x;
+  WinState* st = P.ws + w;
+  if (!st->active) return;
+  window_gradient_check(P, lm, P.wd[w], st, red, mode);
+}
+
+// ------------------------------------------------------------------------------------------
+// ceres::Problem::Evaluate twin: one thread per observation, residual + Jacobians to HBM
+// (k_residual_jacobian of the design; also the kernel measured against the 184 B/obs figure)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_residual_jacobian(CameraK K, LmParams lm, int apply_loss, long long n_obs,
+                                                              const double* __restrict__ poses,
+                                                              const double* __restrict__ points,
+                                                              const int* __restrict__ obs_pose,
+                                                              const int* __restrict__ obs_point,
+                                                              const double* __restrict__ obs_uv, double* res,
+                                                              double* jac_pose, double* jac_point, double* cost_part) {
+  __shared__ double red[4];
+  const long long o = (long long)blockIdx.x * kBlock + threadIdx.x;
+  double c[1] = {0.0};
+  if (o < n_obs) {
+    const double2 uv = reinterpret_cast<const double2*>(obs_uv)[o];
+    double r[2], Jc[12], Jp[6];
+    LmParams l2 = lm;
+    if (!apply_loss) l2.loss = HIPBA_LOSS_NONE;
+    c[0] = eval_obs<true>(K, l2, poses + 7ll * obs_pose[o], points + 3ll * obs_point[o], uv.x, uv.y, nullptr, nullptr,
+                          r, Jc, Jp);
+    if (res) reinterpret_cast<double2*>(res)[o] = make_double2(r[0], r[1]);
+    if (jac_pose) {
+      double2* jp = reinterpret_cast<double2*>(jac_pose + 12 * o);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) jp[i] = make_double2(Jc[2 * i], Jc[2 * i + 1]);
+    }
+    if (jac_point) {
+      double2* jq = reinterpret_cast<double2*>(jac_point + 6 * o);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) jq[i] = make_double2(Jp[2 * i], Jp[2 * i + 1]);
+    }
+  }
+  block_sum<1>(c, red);
+  if (threadIdx.x == 0 && cost_part) cost_part[blockIdx.x] = c[0];
+}
+
+__global__ void k_sum_serial(const double* v, long long n, double* out) {
+  // single workgroup, fixed order
+  __shared__ double red[4];
+  double a[1] = {0.0};
+  for (long long i = threadIdx.x; i < n; i += kBlock) a[0] += v[i];
+  block_sum<1>(a, red);
+  if (threadIdx.x == 0) *out = a[0];
+}
+
+__global__ void k_count_active(DevP P, int* out) {
+  __shared__ int cnt;
+  if (threadIdx.x == 0) cnt = 0;
+  __syncthreads();
+  int c = 0;
+  for (int w = threadIdx.x; w < P.n_windows; w += blockDim.x) c += P.ws[w].active ? 1 : 0;
+  if (c) atomicAdd(&cnt, c);
+  __syncthreads();
+  if (threadIdx.x == 0) *out = cnt;
+}
+
+// ------------------------------------------------------------------------------------------
+// launch wrappers (called from the host driver)
+// ------------------------------------------------------------------------------------------
+size_t schur_lds_bytes(int max_ncam_lds) {
+  size_t base = (size_t)kBlock * 36 * 8 + (size_t)kBlock * 4 + 8 * 8;
+  if (max_ncam_lds > 0) base += ((size_t)max_ncam_lds * (max_ncam_lds + 1) / 2 * 36 + 6 * (size_t)max_ncam_lds) * 8;
+  return base;
+}
+
+hipError_t launch_cost(const DevP& P, const LmParams& lm, int blk_off, int n_blk, int which, int ignore_active,
+                       bool second_bank, hipStream_t s) {
+  if (n_blk <= 0) return hipSuccess;
+  DevP Q = P;
+  if (second_bank) Q.partial = P.partial + ((long long)P.n_blk_pm + P.n_blk_vc + P.n_blk_cc) * kPartialStride;
+  hipLaunchKernelGGL(k_cost, dim3(n_blk), dim3(kBlock), 0, s, Q, lm, blk_off, which, ignore_active);
+  return hipGetLastError();
+}
+
+hipError_t launch_camera_blocks(const DevP& P, const LmParams& lm, int use_scale, hipStream_t s) {
+  if (P.n_act_poses <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_camera_blocks, dim3(P.n_act_poses), dim3(kBlock), 0, s, P, lm, use_scale);
+  return hipGetLastError();
+}
+
+hipError_t launch_make_scale_c(const DevP& P, int jacobi, hipStream_t s) {
+  if (P.n_act_poses <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_make_scale_c, dim3((P.n_act_poses + 255) / 256), dim3(256), 0, s, P, jacobi);
+  return hipGetLastError();
+}
+
+hipError_t launch_point_colnorm(const DevP& P, const LmParams& lm, hipStream_t s) {
+  if (P.n_blk_pm <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_point_colnorm, dim3(P.n_blk_pm), dim3(kBlock), 0, s, P, lm);
+  return hipGetLastError();
+}
+
+hipError_t launch_init_reduced(const DevP& P, const LmParams& lm, int owner, hipStream_t s) {
+  if (P.n_act_poses <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_init_reduced, dim3((P.n_act_poses + 255) / 256), dim3(256), 0, s, P, lm, owner);
+  return hipGetLastError();
+}
+
+hipError_t launch_point_schur(const DevP& P, const LmParams& lm, int lds_acc_ncam, hipStream_t s) {
+  if (P.n_blk_pm <= 0) return hipSuccess;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_point_schur<false>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_point_schur<true>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  const size_t lds = schur_lds_bytes(lds_acc_ncam);
+  if (lds_acc_ncam > 0)
+    hipLaunchKernelGGL(k_point_schur<true>, dim3(P.n_blk_pm), dim3(kBlock), lds, s, P, lm);
+  else
+    hipLaunchKernelGGL(k_point_schur<false>, dim3(P.n_blk_pm), dim3(kBlock), lds, s, P, lm);
+  return hipGetLastError();
+}
+
+hipError_t launch_window_solve_small(const DevP& P, const LmParams& lm, int max_n, hipStream_t s) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_window_solve_small),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    attr_done = true;
+  }
+  const size_t lds = ((size_t)(max_n + 1) * (max_n + 2) / 2 + 10) * 8 + 16;
+  hipLaunchKernelGGL(k_window_solve_small, dim3(P.n_windows), dim3(kBlock), lds, s, P, lm);
+  return hipGetLastError();
+}
+
+hipError_t launch_window_gradient(const DevP& P, const LmParams& lm, int mode, hipStream_t s) {
+  hipLaunchKernelGGL(k_window_gradient, dim3(P.n_windows), dim3(kBlock), 0, s, P, lm, mode);
+  return hipGetLastError();
+}
+
+hipError_t launch_backsub(const DevP& P, const LmParams& lm, hipStream_t s) {
+  const int nb = P.n_blk_pm + P.n_blk_vc;
+  if (nb <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_backsub, dim3(nb), dim3(kBlock), 0, s, P, lm);
+  return hipGetLastError();
+}
+
+hipError_t launch_pose_update(const DevP& P, hipStream_t s) {
+  hipLaunchKernelGGL(k_pose_update, dim3(P.n_windows), dim3(kBlock), 0, s, P);
+  return hipGetLastError();
+}
+
+hipError_t launch_window_init(const DevP& P, const LmParams& lm, int mode, hipStream_t s) {
+  hipLaunchKernelGGL(k_window_init, dim3(P.n_windows), dim3(kBlock), 0, s, P, lm, mode);
+  return hipGetLastError();
+}
+
+hipError_t launch_window_control(const DevP& P, const LmParams& lm, int mode, hipStream_t s) {
+  hipLaunchKernelGGL(k_window_control, dim3(P.n_windows), dim3(kBlock), 0, s, P, lm, mode);
+  return hipGetLastError();
+}
+
+hipError_t launch_count_active(const DevP& P, int* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_count_active, dim3(1), dim3(256), 0, s, P, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_residual_jacobian(const CameraK& K, const LmParams& lm, int apply_loss, long long n_obs,
+                                    const double* poses, const double* points, const int* obs_pose,
+                                    const int* obs_point, const double* obs_uv, double* res, double* jc, double* jp,
+                                    double* cost_part, double* cost_out, hipStream_t s) {
+  if (n_obs <= 0) return hipSuccess;
+  const long long nb = (n_obs + kBlock - 1) / kBlock;
+  hipLaunchKernelGGL(k_residual_jacobian, dim3((unsigned)nb), dim3(kBlock), 0, s, K, lm, apply_loss, n_obs, poses,
+                     points, obs_pose, obs_point, obs_uv, res, jc, jp, cost_part);
+  if (cost_part && cost_out) hipLaunchKernelGGL(k_sum_serial, dim3(1), dim3(kBlock), 0, s, cost_part, nb, cost_out);
+  return hipGetLastError();
+}
+
+}  // namespace hipba

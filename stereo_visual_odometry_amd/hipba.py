@@ -1,0 +1,336 @@
+"""ctypes binding of libhipba.so (include/hipba.h) -- the MI355X bundle-adjustment engine.
+
+The binding mirrors the C ABI one to one; there is no Python or CPU fallback: if the
+shared library is missing or no gfx950 device is visible, construction fails loudly.
+The reference call this stands in for is ``ceres::Solve`` inside
+``VO::Optimizer::optimize`` (reference: src/solve/optimizer.cpp:14-63).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libhipba.so")
+
+OK = 0
+ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_OUT_OF_MEMORY, ERR_UNSUPPORTED, ERR_COMM = -1, -2, -3, -4, -5, -6
+CAMERA_Z_FORWARD, CAMERA_X_FORWARD = 0, 1
+LOSS_NONE, LOSS_HUBER = 0, 1
+LINEAR_AUTO, LINEAR_DENSE_CHOLESKY, LINEAR_PCG = 0, 1, 2
+CONVERGENCE, NO_CONVERGENCE, FAILURE = 0, 1, 2
+REDUCE_SUM, REDUCE_MAX = 0, 1
+(KERNEL_RESIDUAL, KERNEL_RESIDUAL_JACOBIAN, KERNEL_CAMERA_BLOCKS, KERNEL_POINT_SCHUR, KERNEL_BACKSUB,
+ KERNEL_REDUCED_SOLVE) = range(6)
+KERNEL_NAMES = ["residual", "residual_jacobian", "camera_blocks", "point_schur", "backsub", "reduced_solve"]
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_bp = C.POINTER(C.c_uint8)
+
+
+class CProblem(C.Structure):
+    _fields_ = [
+        ("n_poses", C.c_int32), ("poses", _dp), ("pose_const", _bp),
+        ("n_points", C.c_int32), ("points", _dp), ("point_const", _bp),
+        ("n_obs", C.c_int64), ("obs_pose", _ip), ("obs_point", _ip), ("obs_uv", _dp),
+        ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+        ("camera_model", C.c_int32),
+    ]
+
+
+class COptions(C.Structure):
+    _fields_ = [
+        ("max_num_iterations", C.c_int32), ("loss", C.c_int32), ("loss_scale", C.c_double),
+        ("linear_solver", C.c_int32), ("jacobi_scaling", C.c_int32),
+        ("initial_trust_region_radius", C.c_double), ("max_trust_region_radius", C.c_double),
+        ("min_trust_region_radius", C.c_double), ("min_relative_decrease", C.c_double),
+        ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
+        ("max_num_consecutive_invalid_steps", C.c_int32),
+        ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double),
+        ("parameter_tolerance", C.c_double),
+        ("pcg_max_iterations", C.c_int32), ("pcg_tolerance", C.c_double),
+        ("minimizer_progress_to_stdout", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class CIteration(C.Structure):
+    _fields_ = [
+        ("iteration", C.c_int32), ("step_is_valid", C.c_int32), ("step_is_successful", C.c_int32),
+        ("linear_solver_iterations", C.c_int32),
+        ("cost", C.c_double), ("cost_change", C.c_double), ("gradient_max_norm", C.c_double),
+        ("gradient_norm", C.c_double), ("step_norm", C.c_double), ("relative_decrease", C.c_double),
+        ("trust_region_radius", C.c_double),
+    ]
+
+
+class CSummary(C.Structure):
+    _fields_ = [
+        ("termination_type", C.c_int32), ("num_iterations", C.c_int32),
+        ("num_successful_steps", C.c_int32), ("num_unsuccessful_steps", C.c_int32),
+        ("initial_cost", C.c_double), ("final_cost", C.c_double), ("fixed_cost", C.c_double),
+        ("num_active_poses", C.c_int32), ("num_active_points", C.c_int32),
+        ("num_active_observations", C.c_int64),
+        ("time_setup_s", C.c_double), ("time_solve_s", C.c_double), ("time_total_s", C.c_double),
+        ("linear_solver_used", C.c_int32), ("reserved", C.c_int32),
+        ("iteration_log", C.POINTER(CIteration)), ("iteration_log_capacity", C.c_int32), ("reserved2", C.c_int32),
+    ]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
+
+
+class CComm(C.Structure):
+    _fields_ = [("allreduce", ALLREDUCE_FN), ("ctx", C.c_void_p), ("rank", C.c_int32), ("world_size", C.c_int32)]
+
+
+# every symbol include/hipba.h declares
+EXPORTED_SYMBOLS = [
+    "hipba_version", "hipba_last_error", "hipba_options_default", "hipba_create", "hipba_destroy", "hipba_stream",
+    "hipba_solve", "hipba_solve_batched", "hipba_evaluate", "hipba_upload", "hipba_upload_shard", "hipba_reset", "hipba_solve_device",
+    "hipba_solve_device_sharded", "hipba_download", "hipba_free_problem", "hipba_time_kernel",
+]
+
+
+class HipbaError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("hipba error %d: %s" % (code, message))
+        self.code = code
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen libhipba.so and declare its prototypes.  Raises if it is not there."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise ImportError("libhipba.so not found at %s: run ./build.sh (or __graft_entry__.build()); "
+                          "there is no CPU fallback" % p)
+    lib = C.CDLL(p)
+    lib.hipba_version.restype = C.c_int
+    lib.hipba_last_error.restype = C.c_char_p
+    lib.hipba_options_default.argtypes = [C.POINTER(COptions)]
+    lib.hipba_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    lib.hipba_destroy.argtypes = [C.c_void_p]
+    lib.hipba_stream.argtypes = [C.c_void_p]
+    lib.hipba_stream.restype = C.c_void_p
+    lib.hipba_solve.argtypes = [C.c_void_p, C.POINTER(CProblem), C.POINTER(COptions), C.POINTER(CSummary)]
+    lib.hipba_solve_batched.argtypes = [C.c_void_p, C.c_int32, C.POINTER(CProblem), C.POINTER(COptions),
+                                        C.POINTER(CSummary)]
+    lib.hipba_evaluate.argtypes = [C.c_void_p, C.POINTER(CProblem), C.POINTER(COptions), C.c_int, _dp, _dp, _dp, _dp]
+    lib.hipba_upload.argtypes = [C.c_void_p, C.c_int32, C.POINTER(CProblem), C.POINTER(C.c_void_p)]
+    lib.hipba_upload_shard.argtypes = [C.c_void_p, C.POINTER(CProblem), C.POINTER(C.c_void_p)]
+    lib.hipba_reset.argtypes = [C.c_void_p, C.c_void_p]
+    lib.hipba_solve_device.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(COptions), C.POINTER(CSummary)]
+    lib.hipba_solve_device_sharded.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(CComm), C.POINTER(COptions),
+                                               C.POINTER(CSummary)]
+    lib.hipba_download.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, _dp, _dp]
+    lib.hipba_free_problem.argtypes = [C.c_void_p, C.c_void_p]
+    lib.hipba_time_kernel.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(COptions), C.c_int32, C.c_int32, _dp]
+    for name in EXPORTED_SYMBOLS:
+        getattr(lib, name)  # AttributeError if the library lacks a declared entry point
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != OK:
+        raise HipbaError(rc, (load_library().hipba_last_error() or b"").decode("utf-8", "replace"))
+
+
+def default_options(**kw):
+    o = COptions()
+    load_library().hipba_options_default(C.byref(o))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise AttributeError(k)
+        setattr(o, k, v)
+    return o
+
+
+def reference_production_options(**kw):
+    """The options VO::Optimizer::optimize sets (reference: src/solve/optimizer.cpp:54-58)."""
+    return default_options(max_num_iterations=300, **kw)
+
+
+class Problem:
+    """One window as flat arrays (copies its inputs).  poses [N,7] qx qy qz qw tx ty tz, points [M,3],
+    observations (pose index, point index, u, v); K = (fx, fy, cx, cy)."""
+
+    def __init__(self, poses, points, obs_pose, obs_point, obs_uv, K, camera_model=CAMERA_Z_FORWARD,
+                 pose_const=None, point_const=None):
+        self.poses = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 7).copy()
+        self.points = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3).copy()
+        self.obs_pose = np.ascontiguousarray(obs_pose, dtype=np.int32).copy()
+        self.obs_point = np.ascontiguousarray(obs_point, dtype=np.int32).copy()
+        self.obs_uv = np.ascontiguousarray(obs_uv, dtype=np.float64).reshape(-1, 2).copy()
+        self.K = tuple(float(k) for k in K)
+        self.camera_model = int(camera_model)
+        self.pose_const = None if pose_const is None else np.ascontiguousarray(pose_const, dtype=np.uint8).copy()
+        self.point_const = None if point_const is None else np.ascontiguousarray(point_const, dtype=np.uint8).copy()
+
+    def copy(self):
+        return Problem(self.poses, self.points, self.obs_pose, self.obs_point, self.obs_uv, self.K,
+                       self.camera_model, self.pose_const, self.point_const)
+
+    def c(self):
+        p = CProblem()
+        p.n_poses = self.poses.shape[0]
+        p.poses = self.poses.ctypes.data_as(_dp)
+        p.pose_const = None if self.pose_const is None else self.pose_const.ctypes.data_as(_bp)
+        p.n_points = self.points.shape[0]
+        p.points = self.points.ctypes.data_as(_dp)
+        p.point_const = None if self.point_const is None else self.point_const.ctypes.data_as(_bp)
+        p.n_obs = self.obs_pose.shape[0]
+        p.obs_pose = self.obs_pose.ctypes.data_as(_ip)
+        p.obs_point = self.obs_point.ctypes.data_as(_ip)
+        p.obs_uv = self.obs_uv.ctypes.data_as(_dp)
+        p.fx, p.fy, p.cx, p.cy = self.K
+        p.camera_model = self.camera_model
+        return p
+
+
+def _summary_dict(s, log=None):
+    d = {f[0]: getattr(s, f[0]) for f in CSummary._fields_ if f[0] not in ("iteration_log", "reserved", "reserved2")}
+    if log is not None:
+        d["iterations"] = [{f[0]: getattr(log[i], f[0]) for f in CIteration._fields_}
+                           for i in range(min(s.num_iterations, len(log)))]
+    return d
+
+
+class DeviceProblem:
+    """Windows resident in HBM (hipba_upload)."""
+
+    def __init__(self, solver, problems, shard=False):
+        self.solver = solver
+        self.problems = list(problems)
+        arr = (CProblem * len(self.problems))(*[p.c() for p in self.problems])
+        self._h = C.c_void_p()
+        if shard:
+            _check(solver._lib.hipba_upload_shard(solver._h, arr, C.byref(self._h)))
+        else:
+            _check(solver._lib.hipba_upload(solver._h, len(self.problems), arr, C.byref(self._h)))
+
+    @property
+    def n_windows(self):
+        return len(self.problems)
+
+    def reset(self):
+        _check(self.solver._lib.hipba_reset(self.solver._h, self._h))
+
+    def solve(self, options=None, log=False):
+        o = options if options is not None else default_options()
+        n = self.n_windows
+        summ = (CSummary * n)()
+        logs = []
+        if log:
+            for w in range(n):
+                lg = (CIteration * (o.max_num_iterations + 2))()
+                logs.append(lg)
+                summ[w].iteration_log = lg
+                summ[w].iteration_log_capacity = len(lg)
+        _check(self.solver._lib.hipba_solve_device(self.solver._h, self._h, C.byref(o), summ))
+        return [_summary_dict(summ[w], logs[w] if log else None) for w in range(n)]
+
+    def solve_sharded(self, comm, options=None):
+        o = options if options is not None else default_options()
+        summ = CSummary()
+        _check(self.solver._lib.hipba_solve_device_sharded(self.solver._h, self._h, C.byref(comm), C.byref(o),
+                                                           C.byref(summ)))
+        return _summary_dict(summ)
+
+    def download(self, window=0):
+        p = self.problems[window]
+        poses = np.zeros_like(p.poses)
+        points = np.zeros_like(p.points)
+        _check(self.solver._lib.hipba_download(self.solver._h, self._h, window, poses.ctypes.data_as(_dp),
+                                               points.ctypes.data_as(_dp)))
+        return poses, points
+
+    def time_kernel(self, kernel, repeats=10, options=None):
+        o = options if options is not None else default_options()
+        ms = C.c_double(0.0)
+        _check(self.solver._lib.hipba_time_kernel(self.solver._h, self._h, C.byref(o), kernel, repeats,
+                                                  C.cast(C.byref(ms), _dp)))
+        return ms.value
+
+    def free(self):
+        if self._h:
+            self.solver._lib.hipba_free_problem(self.solver._h, self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Solver:
+    """One handle = one GPU + one stream (hipba_create)."""
+
+    def __init__(self, device=0):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        _check(self._lib.hipba_create(int(device), C.byref(self._h)))
+
+    @property
+    def stream(self):
+        return self._lib.hipba_stream(self._h)
+
+    def close(self):
+        if self._h:
+            self._lib.hipba_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def solve(self, problem, options=None, log=True):
+        """hipba_solve: optimises problem.poses / problem.points in place."""
+        return self.solve_batched([problem], options, log)[0]
+
+    def solve_batched(self, problems, options=None, log=False):
+        o = options if options is not None else default_options()
+        n = len(problems)
+        arr = (CProblem * n)(*[p.c() for p in problems])
+        summ = (CSummary * n)()
+        logs = []
+        if log:
+            for w in range(n):
+                lg = (CIteration * (o.max_num_iterations + 2))()
+                logs.append(lg)
+                summ[w].iteration_log = lg
+                summ[w].iteration_log_capacity = len(lg)
+        _check(self._lib.hipba_solve_batched(self._h, n, arr, C.byref(o), summ))
+        return [_summary_dict(summ[w], logs[w] if log else None) for w in range(n)]
+
+    def evaluate(self, problem, options=None, apply_loss=True):
+        """hipba_evaluate: dict(cost, residuals [N,2], jac_pose [N,2,6], jac_point [N,2,3])."""
+        o = options if options is not None else default_options()
+        n = problem.obs_pose.shape[0]
+        res = np.zeros((n, 2))
+        jc = np.zeros((n, 2, 6))
+        jp = np.zeros((n, 2, 3))
+        cost = C.c_double(0.0)
+        cp = problem.c()
+        _check(self._lib.hipba_evaluate(self._h, C.byref(cp), C.byref(o), int(bool(apply_loss)),
+                                        C.cast(C.byref(cost), _dp), res.ctypes.data_as(_dp),
+                                        jc.ctypes.data_as(_dp), jp.ctypes.data_as(_dp)))
+        return {"cost": cost.value, "residuals": res, "jac_pose": jc, "jac_point": jp}
+
+    def upload(self, problems):
+        if isinstance(problems, Problem):
+            problems = [problems]
+        return DeviceProblem(self, problems)
+
+    def upload_shard(self, shard):
+        return DeviceProblem(self, [shard], shard=True)

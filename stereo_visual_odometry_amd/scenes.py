@@ -1,0 +1,201 @@
+"""Synthetic bundle-adjustment workloads (numpy, seeded) shaped like the reference's inputs.
+
+The reference runs BA on KITTI odometry windows built by its OpenCV frontend
+(reference: src/frontend.cpp:70-78, include/visual_odometry/sensor/map.hpp:24); neither
+KITTI nor OpenCV is available here, so windows are generated with the KITTI camera
+(reference: test/ba_test.cpp:23-28), the z-forward convention of the production functor
+(reference: include/visual_odometry/solve/optimizer.hpp:56-57) and the production
+constant-block rule (reference: src/solve/optimizer.cpp:28-36).
+
+  kitti_like_window   <=30 keyframes along +z, ~800 tracked features per frame
+  small_window        10 keyframes x 2000 landmarks x ~15000 observations
+  bal_scale           camera grid x many landmarks, every landmark seen by exactly `degree` cameras
+"""
+import numpy as np
+
+from . import hipba
+
+FX, FY, CX, CY = 718.856, 718.856, 607.1928, 185.2157
+WIDTH, HEIGHT = 1241.0, 376.0
+KITTI_K = (FX, FY, CX, CY)
+
+
+def _quat_from_rotvec(w):
+    w = np.atleast_2d(w)
+    th = np.linalg.norm(w, axis=1, keepdims=True)
+    half = 0.5 * th
+    k = np.where(th > 1e-12, np.sin(half) / np.maximum(th, 1e-300), 0.5)
+    return np.concatenate([k * w, np.cos(half)], axis=1)
+
+
+def _quat_mul(a, b):
+    ax, ay, az, aw = a[..., 0], a[..., 1], a[..., 2], a[..., 3]
+    bx, by, bz, bw = b[..., 0], b[..., 1], b[..., 2], b[..., 3]
+    return np.stack([aw * bx + ax * bw + ay * bz - az * by,
+                     aw * by + ay * bw + az * bx - ax * bz,
+                     aw * bz + az * bw + ax * by - ay * bx,
+                     aw * bw - ax * bx - ay * by - az * bz], axis=-1)
+
+
+def _rotate(q, p):
+    qv = q[..., :3]
+    uv = 2.0 * np.cross(qv, p)
+    return p + q[..., 3:4] * uv + np.cross(qv, uv)
+
+
+def _to_camera(pose, p):
+    """R(q)^T (p - t), vectorised over matching leading dims."""
+    qi = pose[..., :4] * np.array([-1.0, -1.0, -1.0, 1.0])
+    return _rotate(qi, p - pose[..., 4:7])
+
+
+def _project_z(pc):
+    return np.stack([FX * pc[..., 0] / pc[..., 2] + CX, FY * pc[..., 1] / pc[..., 2] + CY], axis=-1)
+
+
+def _perturb_poses(rng, poses, sigma_t, sigma_w):
+    n = poses.shape[0]
+    dq = _quat_from_rotvec(rng.normal(0.0, sigma_w, (n, 3)))
+    out = poses.copy()
+    q = _quat_mul(poses[:, :4], dq)
+    out[:, :4] = q / np.linalg.norm(q, axis=1, keepdims=True)
+    out[:, 4:7] += rng.normal(0.0, sigma_t, (n, 3))
+    return out
+
+
+def _window(rng, n_frames, n_tracks, len_lo, len_hi, geometric_mean=None, pixel_sigma=0.3, sigma_t=0.05,
+            sigma_w=0.005, depth_lo=4.0, depth_hi=60.0):
+    """Keyframes 0.8-1.2 m apart along +z with small yaw; each landmark is tracked over a contiguous run of
+    keyframes.  Returns (gt_poses, gt_points, noisy_poses, noisy_points, obs_pose, obs_point, obs_uv)."""
+    steps = rng.uniform(0.8, 1.2, n_frames)
+    z = np.cumsum(steps) - steps[0]
+    yaw = rng.normal(0.0, 0.01, n_frames)
+    poses = np.zeros((n_frames, 7))
+    poses[:, :4] = _quat_from_rotvec(np.stack([np.zeros(n_frames), yaw, np.zeros(n_frames)], axis=1))
+    poses[:, 4] = rng.normal(0.0, 0.02, n_frames)
+    poses[:, 6] = z
+    if geometric_mean is not None:
+        length = np.minimum(rng.geometric(1.0 / geometric_mean, n_tracks) + 1, n_frames)
+    else:
+        length = rng.integers(len_lo, len_hi + 1, n_tracks)
+    length = np.minimum(length, n_frames)
+    start = (rng.uniform(0.0, 1.0, n_tracks) * (n_frames - length + 1)).astype(np.int64)
+    mid = start  # the landmark is placed in the frustum of the first keyframe that tracks it
+    u = rng.uniform(40.0, WIDTH - 40.0, n_tracks)
+    v = rng.uniform(20.0, HEIGHT - 20.0, n_tracks)
+    d = rng.uniform(depth_lo, depth_hi, n_tracks) + (length * 1.2)  # stays in front of the whole run
+    pc = np.stack([(u - CX) / FX * d, (v - CY) / FY * d, d], axis=1)
+    points = _rotate(poses[mid, :4], pc) + poses[mid, 4:7]
+    # observations: frames start..start+length-1
+    rep = np.repeat(np.arange(n_tracks), length)
+    offs = np.arange(rep.shape[0]) - np.repeat(np.cumsum(length) - length, length)
+    obs_pose = (start[rep] + offs).astype(np.int32)
+    obs_point = rep.astype(np.int32)
+    pcam = _to_camera(poses[obs_pose], points[obs_point])
+    uv = _project_z(pcam)
+    ok = (pcam[:, 2] > 1.0) & (uv[:, 0] >= 0) & (uv[:, 0] < WIDTH) & (uv[:, 1] >= 0) & (uv[:, 1] < HEIGHT)
+    obs_pose, obs_point, uv = obs_pose[ok], obs_point[ok], uv[ok]
+    uv = (uv + rng.normal(0.0, pixel_sigma, uv.shape)).astype(np.float32).astype(np.float64)  # cv::Point2f
+    noisy_poses = _perturb_poses(rng, poses, sigma_t, sigma_w)
+    noisy_poses[0] = poses[0]
+    # triangulation-like depth noise: sigma_z ~ z^2 / (fx * baseline) * 0.3 px, along the viewing ray
+    dz = rng.normal(0.0, 1.0, n_tracks) * (d ** 2) / (FX * 0.54) * 0.3
+    noisy_points = points + _rotate(poses[mid, :4], pc / d[:, None] * dz[:, None])
+    return poses, points, noisy_poses, noisy_points, obs_pose, obs_point, uv
+
+
+def _production_constants(n_frames, n_points, obs_pose, obs_point):
+    """optimizer.cpp:28-36: first frame constant, and every landmark it observes."""
+    pose_const = np.zeros(n_frames, dtype=np.uint8)
+    pose_const[0] = 1
+    point_const = np.zeros(n_points, dtype=np.uint8)
+    point_const[obs_point[obs_pose == 0]] = 1
+    return pose_const, point_const
+
+
+def kitti_like_window(seed, n_frames=30, features_per_frame=800, mean_track=6.0):
+    """One sliding window as the reference's frontend would hand it to BA (production semantics)."""
+    rng = np.random.default_rng(seed)
+    n_tracks = int(features_per_frame * n_frames / mean_track)
+    gt_p, gt_q, poses, points, op, oq, uv = _window(rng, n_frames, n_tracks, 2, n_frames, geometric_mean=mean_track)
+    pc, qc = _production_constants(n_frames, n_tracks, op, oq)
+    prob = hipba.Problem(poses, points, op, oq, uv, KITTI_K, hipba.CAMERA_Z_FORWARD, pc, qc)
+    return prob, gt_p, gt_q
+
+
+def small_window(seed, n_frames=10, n_points=2000):
+    """10 keyframes x 2000 landmarks, each seen by a contiguous run of 5..10 keyframes (~15000 observations)."""
+    rng = np.random.default_rng(seed)
+    gt_p, gt_q, poses, points, op, oq, uv = _window(rng, n_frames, n_points, 5, n_frames)
+    pc, qc = _production_constants(n_frames, n_points, op, oq)
+    prob = hipba.Problem(poses, points, op, oq, uv, KITTI_K, hipba.CAMERA_Z_FORWARD, pc, qc)
+    return prob, gt_p, gt_q
+
+
+def bal_scale(seed=3000, grid=(40, 50), n_points=1_000_000, degree=8, pitch=2.0, pixel_sigma=0.5,
+              sigma_t=0.05, sigma_w=0.005, sigma_p=0.1, depth_lo=10.0, depth_hi=80.0):
+    """Cameras on a grid in the z=0 plane looking along +z with attitude jitter; landmarks uniform in the
+    union frustum, each observed by exactly `degree` of the cameras that see it; camera 0 constant.
+    Observations come out sorted by landmark."""
+    rng = np.random.default_rng(seed)
+    gx, gy = grid
+    n_cams = gx * gy
+    ix, iy = np.meshgrid(np.arange(gx), np.arange(gy), indexing="ij")
+    poses = np.zeros((n_cams, 7))
+    poses[:, :4] = _quat_from_rotvec(rng.normal(0.0, 0.05, (n_cams, 3)))
+    poses[:, 4] = ix.ravel() * pitch
+    poses[:, 5] = iy.ravel() * pitch
+    # landmark positions; a camera at (cx, cy) sees (X, Y, Z) when |X-cx| < tx*Z and |Y-cy| < ty*Z (no jitter)
+    tx, ty = 0.80, 0.24
+    Z = rng.uniform(depth_lo, depth_hi, n_points)
+    X = rng.uniform(0.0, (gx - 1) * pitch, n_points)
+    Y = rng.uniform(0.0, (gy - 1) * pitch, n_points)
+    x0 = np.clip(np.ceil((X - tx * Z) / pitch), 0, gx - 1).astype(np.int64)
+    x1 = np.clip(np.floor((X + tx * Z) / pitch), 0, gx - 1).astype(np.int64)
+    y0 = np.clip(np.ceil((Y - ty * Z) / pitch), 0, gy - 1).astype(np.int64)
+    y1 = np.clip(np.floor((Y + ty * Z) / pitch), 0, gy - 1).astype(np.int64)
+    nx, ny = np.maximum(x1 - x0 + 1, 0), np.maximum(y1 - y0 + 1, 0)
+    count = nx * ny
+    keep = count >= degree
+    # landmarks seen by too few cameras are pushed deeper until enough cameras see them
+    while not keep.all():
+        bad = ~keep
+        Z[bad] = rng.uniform(0.5 * (depth_lo + depth_hi), depth_hi, bad.sum())
+        x0[bad] = np.clip(np.ceil((X[bad] - tx * Z[bad]) / pitch), 0, gx - 1)
+        x1[bad] = np.clip(np.floor((X[bad] + tx * Z[bad]) / pitch), 0, gx - 1)
+        y0[bad] = np.clip(np.ceil((Y[bad] - ty * Z[bad]) / pitch), 0, gy - 1)
+        y1[bad] = np.clip(np.floor((Y[bad] + ty * Z[bad]) / pitch), 0, gy - 1)
+        nx, ny = np.maximum(x1 - x0 + 1, 0), np.maximum(y1 - y0 + 1, 0)
+        count = nx * ny
+        keep = count >= degree
+    points = np.stack([X, Y, Z], axis=1)
+    # `degree` distinct cameras per landmark: sorted draws from [0, count-degree] plus 0..degree-1
+    pick = np.sort((rng.uniform(0.0, 1.0, (n_points, degree)) * (count - degree + 1)[:, None]).astype(np.int64), axis=1)
+    pick += np.arange(degree)[None, :]
+    cam = (x0[:, None] + pick // ny[:, None]) * gy + (y0[:, None] + pick % ny[:, None])
+    obs_pose = cam.ravel().astype(np.int32)
+    obs_point = np.repeat(np.arange(n_points, dtype=np.int32), degree)
+    pcam = _to_camera(poses[obs_pose], points[obs_point])
+    uv = _project_z(pcam) + rng.normal(0.0, pixel_sigma, (obs_pose.shape[0], 2))
+    uv = uv.astype(np.float32).astype(np.float64)
+    noisy_poses = _perturb_poses(rng, poses, sigma_t, sigma_w)
+    noisy_poses[0] = poses[0]
+    noisy_points = points + rng.normal(0.0, sigma_p, points.shape)
+    pose_const = np.zeros(n_cams, dtype=np.uint8)
+    pose_const[0] = 1
+    prob = hipba.Problem(noisy_poses, noisy_points, obs_pose, obs_point, uv, KITTI_K, hipba.CAMERA_Z_FORWARD,
+                         pose_const, None)
+    return prob, poses, points
+
+
+def shard_by_point(prob, rank, world_size):
+    """Landmark-aligned observation shard for multi-GPU solves: every rank keeps all poses and a
+    contiguous block of the landmarks with all of their observations.  Landmarks of other ranks are
+    dropped from the shard (they carry no observations here)."""
+    n_points = prob.points.shape[0]
+    lo = (n_points * rank) // world_size
+    hi = (n_points * (rank + 1)) // world_size
+    sel = (prob.obs_point >= lo) & (prob.obs_point < hi)
+    point_const = None if prob.point_const is None else prob.point_const[lo:hi]
+    return hipba.Problem(prob.poses, prob.points[lo:hi], prob.obs_pose[sel], prob.obs_point[sel] - lo,
+                         prob.obs_uv[sel], prob.K, prob.camera_model, prob.pose_const, point_const), (lo, hi)
