@@ -126,7 +126,7 @@ def kitti_like_window(seed, n_frames=30, features_per_frame=800, mean_track=6.0)
 def small_window(seed, n_frames=10, n_points=2000):
     """10 keyframes x 2000 landmarks, each seen by a contiguous run of 5..10 keyframes (~15000 observations)."""
     rng = np.random.default_rng(seed)
-    gt_p, gt_q, poses, points, op, oq, uv = _window(rng, n_frames, n_points, 5, n_frames)
+    gt_p, gt_q, poses, points, op, oq, uv = _window(rng, n_frames, n_points, min(5, n_frames), n_frames)
     pc, qc = _production_constants(n_frames, n_points, op, oq)
     prob = hipba.Problem(poses, points, op, oq, uv, KITTI_K, hipba.CAMERA_Z_FORWARD, pc, qc)
     return prob, gt_p, gt_q

@@ -1,0 +1,81 @@
+"""Generates tests/golden/*.json.  Run once from the repository root:
+
+    python tests/golden/make_golden.py
+
+Inputs: tests/golden/ba_data.txt (the reference's only data fixture, test/ba_data.txt) and seeded
+numpy noise.  Outputs are produced by the CPU oracle (oracle/ba_oracle.c); they pin the oracle
+against accidental change and give the GPU tests fixed expected values.  Because the reference's
+own Ceres build cannot run here, these are NOT outputs of the reference: parity unpinned.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import oracle  # noqa: E402
+from stereo_visual_odometry_amd import harness, hipba, scenes, vo  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def dump_problem(p):
+    return {
+        "poses": p.poses.tolist(), "points": p.points.tolist(), "obs_pose": p.obs_pose.tolist(),
+        "obs_point": p.obs_point.tolist(), "obs_uv": p.obs_uv.tolist(), "K": list(p.K),
+        "camera_model": p.camera_model,
+        "pose_const": None if p.pose_const is None else p.pose_const.tolist(),
+        "point_const": None if p.point_const is None else p.point_const.tolist(),
+    }
+
+
+def to_oracle(p):
+    return oracle.Problem(p.poses, p.points, p.obs_pose, p.obs_point, p.obs_uv, p.K, p.camera_model,
+                          p.pose_const, p.point_const)
+
+
+def case(name, prob, loss, loss_scale, max_it):
+    o = to_oracle(prob)
+    ev_a = oracle.evaluate(o, oracle.JAC_ANALYTIC, loss, loss_scale, apply_loss=True)
+    ev_n = oracle.evaluate(o, oracle.JAC_NUMERIC, loss, loss_scale, apply_loss=True)
+    out = {"name": name, "problem": dump_problem(prob), "loss": loss, "loss_scale": loss_scale,
+           "max_num_iterations": max_it,
+           "evaluate": {"cost": ev_a["cost"], "residuals": ev_a["residuals"].tolist(),
+                        "jac_pose_analytic": ev_a["jac_pose"].tolist(), "jac_point_analytic": ev_a["jac_point"].tolist(),
+                        "jac_pose_numeric": ev_n["jac_pose"].tolist(), "jac_point_numeric": ev_n["jac_point"].tolist()}}
+    for mode, key in ((oracle.JAC_ANALYTIC, "solve_analytic"), (oracle.JAC_NUMERIC, "solve_numeric")):
+        q = to_oracle(prob)
+        s, its = oracle.solve(q, oracle.default_options(loss=loss, loss_scale=loss_scale, max_num_iterations=max_it,
+                                                        jacobian_mode=mode))
+        s.pop("time_evaluate_s"); s.pop("time_linear_solve_s"); s.pop("time_total_s")
+        out[key] = {"summary": s, "iterations": its, "poses": q.poses.tolist(), "points": q.points.tolist()}
+    return out
+
+
+def main():
+    m = harness.makeMapFromData(os.path.join(HERE, "ba_data.txt"))
+    harness.makeFeaturesAndCorrespondence(m)
+    noisy = harness.copyMapAndAddNoise(m, seed=20241008)
+    gt, _ = vo.flatten_map(m, harness.INTRINSICS, hipba.CAMERA_X_FORWARD, first_frame_constant=False)
+    p_test, _ = vo.flatten_map(noisy, harness.INTRINSICS, hipba.CAMERA_X_FORWARD, first_frame_constant=False)
+    p_prod, _ = vo.flatten_map(noisy, harness.INTRINSICS, hipba.CAMERA_X_FORWARD, first_frame_constant=True)
+    # a 3-pose / 20-landmark z-forward window with the production constant rule
+    rng = np.random.default_rng(7)
+    _, _, poses, points, op, oq, uv = scenes._window(rng, 3, 20, 2, 3)
+    pc, qc = scenes._production_constants(3, 20, op, oq)
+    p_z = hipba.Problem(poses, points, op, oq, uv, scenes.KITTI_K, hipba.CAMERA_Z_FORWARD, pc, qc)
+    cases = [
+        case("ba_data_ba_test_semantics", p_test, oracle.LOSS_HUBER, 1.0, 50),
+        case("ba_data_production_semantics", p_prod, oracle.LOSS_NONE, 1.0, 300),
+        case("zforward_3pose_20point_production", p_z, oracle.LOSS_NONE, 1.0, 300),
+    ]
+    doc = {"ground_truth": dump_problem(gt), "cases": cases}
+    with open(os.path.join(HERE, "ba_golden.json"), "w") as f:
+        json.dump(doc, f)
+    print("wrote ba_golden.json", os.path.getsize(os.path.join(HERE, "ba_golden.json")), "bytes")
+
+
+if __name__ == "__main__":
+    main()

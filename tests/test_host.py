@@ -1,0 +1,125 @@
+"""CPU-only: the C-ABI library loads and exports what include/hipba.h declares, and the host logic
+(map flattening, harness, workload generators, sharding) behaves as the reference's does."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR, ROOT
+from stereo_visual_odometry_amd import harness, hipba, scenes, vo
+
+
+def test_library_loads_and_exports_header_symbols():
+    lib = hipba.load_library()
+    header = open(os.path.join(ROOT, "include", "hipba.h")).read()
+    declared = sorted(set(re.findall(r"\b(hipba_[a-z_]+)\s*\(", header)) - {"hipba_allreduce_fn"})
+    assert declared, "no declarations found"
+    for name in declared:
+        assert hasattr(lib, name), "libhipba.so does not export %s" % name
+    assert sorted(hipba.EXPORTED_SYMBOLS) == declared
+    assert lib.hipba_version() == 100
+
+
+def test_options_default_match_ceres_defaults():
+    o = hipba.default_options()
+    assert (o.max_num_iterations, o.jacobi_scaling, o.max_num_consecutive_invalid_steps) == (50, 1, 5)
+    assert (o.initial_trust_region_radius, o.max_trust_region_radius, o.min_trust_region_radius) == (1e4, 1e16, 1e-32)
+    assert (o.min_relative_decrease, o.min_lm_diagonal, o.max_lm_diagonal) == (1e-3, 1e-6, 1e32)
+    assert (o.function_tolerance, o.gradient_tolerance, o.parameter_tolerance) == (1e-6, 1e-10, 1e-8)
+    assert hipba.reference_production_options().max_num_iterations == 300  # optimizer.cpp:58
+
+
+def test_struct_sizes_match_the_c_side(tmp_path):
+    # compile a probe against include/hipba.h with gcc: a layout mismatch would corrupt every call
+    import subprocess
+    src = tmp_path / "probe.c"
+    src.write_text('#include <stdio.h>\n#include "hipba.h"\nint main(void){printf("%zu %zu %zu %zu %zu\\n",'
+                   'sizeof(hipba_problem),sizeof(hipba_options),sizeof(hipba_iteration),sizeof(hipba_summary),'
+                   'sizeof(hipba_comm));return 0;}\n')
+    exe = tmp_path / "probe"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    sizes = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    assert sizes == [ctypes.sizeof(hipba.CProblem), ctypes.sizeof(hipba.COptions), ctypes.sizeof(hipba.CIteration),
+                     ctypes.sizeof(hipba.CSummary), ctypes.sizeof(hipba.CComm)]
+
+
+def test_no_device_fails_loudly_without_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(hipba.HipbaError) as e:
+        hipba.Solver(0)
+    assert e.value.code in (hipba.ERR_NO_DEVICE, hipba.ERR_HIP)
+
+
+def test_flatten_map_applies_reference_constant_rule():
+    m = harness.makeMapFromData(os.path.join(GOLDEN_DIR, "ba_data.txt"))
+    harness.makeFeaturesAndCorrespondence(m)
+    prob, lms = vo.flatten_map(m, harness.INTRINSICS, hipba.CAMERA_X_FORWARD, first_frame_constant=True)
+    assert prob.poses.shape == (5, 7) and prob.points.shape == (25, 3) and prob.obs_pose.shape == (27,)
+    assert prob.pose_const.tolist() == [1, 0, 0, 0, 0]
+    # optimizer.cpp:31-34: exactly the landmarks observed by frame 0 are constant
+    seen0 = set(prob.obs_point[prob.obs_pose == 0].tolist())
+    assert set(np.nonzero(prob.point_const)[0].tolist()) == seen0 and len(seen0) == 11
+    # frames oldest first, one observation per left feature, pixels widened from float32
+    assert prob.obs_pose.tolist() == sorted(prob.obs_pose.tolist())
+    assert np.all(prob.obs_uv == prob.obs_uv.astype(np.float32).astype(np.float64))
+    assert prob.K == (harness.FX, harness.FY, harness.CX, harness.CY)
+    # write_back puts values where they came from
+    prob.poses[:] += 1.0
+    vo.write_back(m, lms, prob)
+    assert np.allclose(m.frames_[2].pose_, prob.poses[2])
+
+
+def test_map_window_is_capped_like_the_reference():
+    m = vo.Map()
+    for i in range(35):
+        m.insertFrame(vo.Frame())
+    assert len(m.frames_) == 30  # sensor/map.hpp:24, map.cpp:12-15
+
+
+def test_noise_is_reproducible_and_matches_golden(golden):
+    m = harness.makeMapFromData(os.path.join(GOLDEN_DIR, "ba_data.txt"))
+    harness.makeFeaturesAndCorrespondence(m)
+    a = harness.copyMapAndAddNoise(m, seed=20241008)
+    prob, _ = vo.flatten_map(a, harness.INTRINSICS, hipba.CAMERA_X_FORWARD, first_frame_constant=False)
+    np.testing.assert_allclose(prob.poses, np.array(golden["cases"][0]["problem"]["poses"]), atol=1e-15)
+    np.testing.assert_allclose(prob.points, np.array(golden["cases"][0]["problem"]["points"]), atol=1e-15)
+    assert np.allclose(np.linalg.norm(prob.poses[:, :4], axis=1), 1.0)
+    assert harness.calculateTotalError(a) > 100.0
+
+
+def test_workload_generators_have_the_configured_shapes():
+    p, gt_p, gt_q = scenes.small_window(2000)
+    assert p.poses.shape == (10, 7) and p.points.shape == (2000, 3)
+    assert 12000 <= p.obs_pose.shape[0] <= 16000
+    assert p.pose_const[0] == 1 and p.pose_const[1:].sum() == 0
+    assert set(np.nonzero(p.point_const)[0]) == set(p.obs_point[p.obs_pose == 0])
+    p2, _, _ = scenes.kitti_like_window(1000)
+    assert p2.poses.shape == (30, 7) and 15000 <= p2.obs_pose.shape[0] <= 45000
+    b, _, _ = scenes.bal_scale(n_points=5000, grid=(8, 10))
+    assert b.poses.shape == (80, 7) and b.obs_pose.shape[0] == 5000 * 8
+    deg = np.bincount(b.obs_point, minlength=5000)
+    assert deg.min() == 8 and deg.max() == 8
+    # a landmark is seen by 8 DISTINCT cameras, observations sorted by landmark
+    assert all(len(set(b.obs_pose[8 * i:8 * i + 8])) == 8 for i in range(0, 5000, 97))
+    assert np.all(np.diff(b.obs_point) >= 0)
+    # seeded
+    b2, _, _ = scenes.bal_scale(n_points=5000, grid=(8, 10))
+    assert np.array_equal(b.obs_uv, b2.obs_uv)
+
+
+def test_shards_partition_landmarks_and_observations():
+    b, _, _ = scenes.bal_scale(n_points=3001, grid=(6, 6))
+    for world in (1, 2, 4, 8):
+        n_obs, covered = 0, np.zeros(3001, dtype=int)
+        for r in range(world):
+            sh, (lo, hi) = scenes.shard_by_point(b, r, world)
+            covered[lo:hi] += 1
+            n_obs += sh.obs_pose.shape[0]
+            assert sh.poses.shape == b.poses.shape  # poses replicated
+            assert sh.obs_point.min() >= 0 and sh.obs_point.max() < hi - lo
+            np.testing.assert_array_equal(sh.points, b.points[lo:hi])
+        assert n_obs == b.obs_pose.shape[0] and np.all(covered == 1)
