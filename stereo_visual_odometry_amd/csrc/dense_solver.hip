@@ -29,7 +29,7 @@ size_t big_work_bytes(int n, int ncam) {
   const size_t npad = rup((size_t)n, NB);
   size_t b = 0;
   b += rup(npad * npad * 8, 256);            // A
-  b += rup((npad / NB) * NB * NB * 8, 256);  // Linv
+  b += 2 * rup((npad / NB) * NB * NB * 8, 256);  // Linv, LinvT
   b += rup(2 * npad * 8, 256);               // rhs, z
   b += rup((6 * npad + kPcgScalars + 3 * (size_t)ncam + 64) * 8, 256);  // pcg vectors + scalars + partials
   b += rup((size_t)36 * ncam * 8, 256);      // Minv
@@ -42,6 +42,7 @@ void big_work_bind(BigWork& W, int n, int ncam, void* base) {
   W.n = n; W.npad = (int)npad;
   W.A = reinterpret_cast<double*>(p); p += rup(npad * npad * 8, 256);
   W.Linv = reinterpret_cast<double*>(p); p += rup((npad / NB) * NB * NB * 8, 256);
+  W.LinvT = reinterpret_cast<double*>(p); p += rup((npad / NB) * NB * NB * 8, 256);
   W.rhs = reinterpret_cast<double*>(p); p += rup(2 * npad * 8, 256);
   W.pcg = reinterpret_cast<double*>(p); p += rup((6 * npad + kPcgScalars + 3 * (size_t)ncam + 64) * 8, 256);
   W.Minv = reinterpret_cast<double*>(p);
@@ -69,72 +70,212 @@ __global__ void k_pad_init(DevP P, double* A, double* rhs, int n, int ld) {
   rhs[col] = col < n ? P.b[6ll * P.wd[0].cam_base + col] : 0.0;
 }
 
-// ---- diagonal block: Cholesky in LDS + explicit inverse of the factor --------------------------
-__device__ __forceinline__ int lidx(int i, int k) { return i * (i + 1) / 2 + k; }
+// ---- diagonal block: Cholesky + explicit inverse of the factor, one workgroup ------------------------
+// The 128x128 block is held in LDS as 16x16 tiles (column-major inside a tile, so that the 16x4
+// operand slab of v_mfma_f64_16x16x4_f64 is 64 consecutive doubles).  Right-looking over the 8 tile
+// columns: wave 0 factors and inverts the 16x16 diagonal tile with scalar code, the panel below it and
+// the trailing tiles are updated on the matrix cores.  L^-1 is then built tile column by tile column
+// (block forward substitution), two tile columns per wave.
+constexpr int TB = 16;
+constexpr int NTL = NB / TB;                      // 8 tile rows
+constexpr int kTile = TB * TB;                    // doubles per tile
+constexpr int kPotrfTiles = NTL * (NTL + 1) / 2 + NTL + 4 * NTL;  // L tiles + diagonal inverses + per-wave X^T tiles
 
-__global__ __launch_bounds__(256) void k_potrf_inv(DevP P, double* A, int ld, int k, double* Linv_all) {
+__device__ __forceinline__ int ltile(int bi, int bj) { return (bi * (bi + 1) / 2 + bj) * kTile; }
+
+// wave-uniform broadcast of lane `src`'s double (src is a compile-time constant after unrolling)
+__device__ __forceinline__ double bcast_lane(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+// acc += M * N^T for two column-major 16x16 tiles (negate: acc -= ...)
+template <bool NEG>
+__device__ __forceinline__ v4d mfma_tile(const double* M, const double* N, v4d acc, int lane) {
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    const int o = (kk * 4 + (lane >> 4)) * TB + (lane & 15);
+    const double a = NEG ? -M[o] : M[o];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, N[o], acc, 0, 0, 0);
+  }
+  return acc;
+}
+// accumulator element r of lane l is D(p, q), p = (l >> 4) + 4 r, q = l & 15
+__device__ __forceinline__ v4d tile_load(const double* T, int lane) {
+  v4d v;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = T[(lane & 15) * TB + (lane >> 4) + 4 * r];
+  return v;
+}
+__device__ __forceinline__ void tile_store(double* T, v4d v, int lane) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) T[(lane & 15) * TB + (lane >> 4) + 4 * r] = v[r];
+}
+__device__ __forceinline__ v4d tile_load_t(const double* T, int lane) {  // loads D^T
+  v4d v;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = T[((lane >> 4) + 4 * r) * TB + (lane & 15)];
+  return v;
+}
+__device__ __forceinline__ void tile_store_t(double* T, v4d v, int lane) {  // stores D^T
+#pragma unroll
+  for (int r = 0; r < 4; ++r) T[((lane >> 4) + 4 * r) * TB + (lane & 15)] = v[r];
+}
+
+template <int PH = 0xff>
+__global__ __launch_bounds__(256) void k_potrf_inv(DevP P, double* A, int ld, int k, double* Linv_all,
+                                                   double* LinvT_all) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   if (!P.ws[0].active || P.ws[0].solve_failed) return;
-  double* L = smem;                      // packed lower, NB*(NB+1)/2
-  double* X = smem + NB * (NB + 1) / 2;  // packed lower inverse
-  int& fail = *reinterpret_cast<int*>(X + NB * (NB + 1) / 2);
-  const int t = threadIdx.x;
-  double* Akk = A + (long long)k * NB * ld + k * NB;
-  for (int e = t; e < NB * NB; e += 256) {
-    const int c = e / NB, r = e % NB;
-    if (r >= c) L[lidx(r, c)] = Akk[(long long)c * ld + r];
+  double* Lt = smem;                                   // 36 tiles
+  double* Dinv = smem + (NTL * (NTL + 1) / 2) * kTile;   // 8 tiles
+  double* XT = Dinv + NTL * kTile;                     // 4 waves x 8 tiles
+  int& fail = *reinterpret_cast<int*>(smem + kPotrfTiles * kTile);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  double* Akk = A + (long long)k * NB * ld + (long long)k * NB;
+  // load the lower tiles: thread t carries element (row t & 15, column t >> 4) of every tile, so the 36
+  // loads are independent and each wave reads 128-byte runs
+  {
+    const int q = t >> 4, pr = t & 15;
+#pragma unroll
+    for (int bi = 0; bi < NTL; ++bi)
+#pragma unroll
+      for (int bj = 0; bj <= bi; ++bj) Lt[ltile(bi, bj) + t] = Akk[(long long)(TB * bj + q) * ld + TB * bi + pr];
   }
   if (t == 0) fail = 0;
   __syncthreads();
-  const int ti = t & 15, tk = t >> 4;
-  for (int j = 0; j < NB; ++j) {
-    const double d = L[lidx(j, j)];
-    if (!(d > 0.0) || !isfinite(d)) {
-      if (t == 0) fail = 1;
-      break;
+
+  for (int j = 0; j < NTL; ++j) {
+    if (wave == 0 && (PH & 1)) {
+      // (a) Cholesky and inverse of the 16x16 diagonal tile in registers: lane r holds row r, the
+      // pivots and multipliers travel between lanes as wave-uniform scalars (v_readlane)
+      double* D = Lt + ltile(j, j);
+      const int r = lane & 15;
+      double x[TB], rinv[TB];
+#pragma unroll
+      for (int c = 0; c < TB; ++c) x[c] = D[c * TB + r];
+      bool bad = false;
+#pragma unroll
+      for (int c = 0; c < TB; ++c) {
+        const double d = bcast_lane(x[c], c);
+        if (!(d > 0.0) || !isfinite(d)) bad = true;
+        // 1/sqrt(d): hardware estimate + two Newton steps (full double precision, no division)
+        double inv = __builtin_amdgcn_rsq(d);
+        inv = inv * (1.5 - 0.5 * d * inv * inv);
+        inv = inv * (1.5 - 0.5 * d * inv * inv);
+        rinv[c] = inv;
+        x[c] *= inv;
+#pragma unroll
+        for (int kc = c + 1; kc < TB; ++kc) x[kc] -= x[c] * bcast_lane(x[c], kc);
+      }
+      if (bad) {
+        if (lane == 0) fail = 1;
+      } else {
+        // lane c owns column c of the inverse (forward substitution; entries above the diagonal come out 0)
+        double y[TB];
+#pragma unroll
+        for (int i = 0; i < TB; ++i) {
+          double acc = (i == r) ? 1.0 : 0.0;
+#pragma unroll
+          for (int tt = 0; tt < i; ++tt) acc -= bcast_lane(x[tt], i) * y[tt];
+          y[i] = acc * rinv[i];
+        }
+        if (lane < TB) {
+#pragma unroll
+          for (int c = 0; c < TB; ++c) {
+            if (c <= r) D[c * TB + r] = x[c];
+            Dinv[j * kTile + r * TB + c] = y[c];   // lane r holds column r of the inverse
+          }
+        }
+      }
     }
-    const double inv = 1.0 / sqrt(d);
     __syncthreads();
-    for (int i = j + t; i < NB; i += 256) L[lidx(i, j)] *= inv;
+    if (fail) break;
+    // (b) panel below the diagonal tile: L(i,j) = A(i,j) * Linv(j,j)^T.  The product is formed transposed
+    // (D = Linv * A^T) so that its store is lane-contiguous in the column-major tile.
+    for (int i = j + 1 + wave; i < NTL && (PH & 2); i += 4) {
+      v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+      acc = mfma_tile<false>(Dinv + j * kTile, Lt + ltile(i, j), acc, lane);
+      tile_store_t(Lt + ltile(i, j), acc, lane);
+    }
     __syncthreads();
-    for (int i = j + 1 + ti; i < NB; i += 16) {
-      const double lij = L[lidx(i, j)];
-      for (int c = j + 1 + tk; c <= i; c += 16) L[lidx(i, c)] -= lij * L[lidx(c, j)];
+    // (c) trailing tiles: A(i2,j2) -= L(i2,j) L(j2,j)^T, again held transposed in the accumulator
+    {
+      int e = 0;
+      for (int i2 = j + 1; i2 < NTL && (PH & 4); ++i2) {
+        for (int j2 = j + 1; j2 <= i2; ++j2, ++e) {
+          if ((e & 3) != wave) continue;
+          double* C = Lt + ltile(i2, j2);
+          v4d acc = tile_load_t(C, lane);
+          acc = mfma_tile<true>(Lt + ltile(j2, j), Lt + ltile(i2, j), acc, lane);
+          tile_store_t(C, acc, lane);
+        }
+      }
     }
     __syncthreads();
   }
-  __syncthreads();
   if (fail) {
     if (t == 0) P.ws[0].solve_failed = 1;
     return;
   }
-  for (int e = t; e < NB * NB; e += 256) {
-    const int c = e / NB, r = e % NB;
-    if (r >= c) Akk[(long long)c * ld + r] = L[lidx(r, c)];
-  }
-  // X = L^-1, thread j owns column j (forward substitution down the column)
-  if (t < NB) {
-    const int j = t;
-    for (int i = 0; i < NB; ++i) {
-      double acc = (i == j) ? 1.0 : 0.0;
-      for (int c = 0; c < i; ++c) {
-        const double xv = (c >= j) ? X[lidx(c, j)] : 0.0;
-        acc -= L[lidx(i, c)] * xv;
-      }
-      if (i >= j) X[lidx(i, j)] = acc / L[lidx(i, i)];
-    }
+  // factor back to global memory (lower part only)
+  {
+    const int q = t >> 4, pr = t & 15;
+#pragma unroll
+    for (int bi = 0; bi < NTL; ++bi)
+#pragma unroll
+      for (int bj = 0; bj <= bi; ++bj)
+        if (bi > bj || pr >= q) Akk[(long long)(TB * bj + q) * ld + TB * bi + pr] = Lt[ltile(bi, bj) + t];
   }
   __syncthreads();
+  // (d) X = L^-1 by tile columns; wave w takes columns w and 7 - w.  X^T tiles of the current column
+  // live in the wave's scratch, the product Y^T in the (now free) diagonal tile slot (w, w).
   double* Linv = Linv_all + (long long)k * NB * NB;
-  for (int e = t; e < NB * NB; e += 256) {
-    const int c = e / NB, r = e % NB;  // Linv(r, c) column-major
-    Linv[e] = (r >= c) ? X[lidx(r, c)] : 0.0;
+  double* LinvT = LinvT_all + (long long)k * NB * NB;
+  double* myXT = XT + wave * NTL * kTile;
+  double* YT = Lt + ltile(wave, wave);
+  for (int pass = 0; pass < 2 && (PH & 8); ++pass) {
+    const int j = pass == 0 ? wave : NTL - 1 - wave;
+    // tiles above the diagonal are zero
+    for (int i = 0; i < j; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+      {
+        Linv[(long long)(TB * j + (lane & 15)) * NB + TB * i + (lane >> 4) + 4 * r] = 0.0;
+        LinvT[(long long)(TB * i + (lane >> 4) + 4 * r) * NB + TB * j + (lane & 15)] = 0.0;
+      }
+    }
+    {
+      const v4d d = tile_load(Dinv + j * kTile, lane);
+      tile_store_t(myXT + j * kTile, d, lane);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+      {
+        Linv[(long long)(TB * j + (lane & 15)) * NB + TB * j + (lane >> 4) + 4 * r] = d[r];
+        LinvT[(long long)(TB * j + (lane >> 4) + 4 * r) * NB + TB * j + (lane & 15)] = d[r];
+      }
+    }
+    for (int i = j + 1; i < NTL; ++i) {
+      v4d y = (v4d){0.0, 0.0, 0.0, 0.0};
+      for (int tt = j; tt < i; ++tt) y = mfma_tile<false>(Lt + ltile(i, tt), myXT + tt * kTile, y, lane);
+      tile_store_t(YT, y, lane);
+      v4d x = (v4d){0.0, 0.0, 0.0, 0.0};
+      x = mfma_tile<true>(Dinv + i * kTile, YT, x, lane);
+      tile_store_t(myXT + i * kTile, x, lane);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+      {
+        Linv[(long long)(TB * j + (lane & 15)) * NB + TB * i + (lane >> 4) + 4 * r] = x[r];
+        LinvT[(long long)(TB * i + (lane >> 4) + 4 * r) * NB + TB * j + (lane & 15)] = x[r];
+      }
+    }
   }
 }
 
 // ---- fp64 matrix-core GEMM, C(i,j) (op)= sum_k A(i,k) B(j,k), column-major, 128x128 tiles ----------
-// MODE 0: trailing update  A22(i,j) -= L(i,k) L(j,k)      (tiles with j > i are skipped)
-// MODE 1: panel solve      L(i,k)   = A(i,k) Linv(k)^T    (in place: the workgroup owns the tile)
+// MODE 0: update        A(i,j) -= sum over panel columns [kcol, kcol + K) of L(i,k) L(j,k)
+//                       (tile rows i0 + blockIdx.x, tile columns j0 + blockIdx.y, tiles with j > i skipped)
+// MODE 1: panel solve   L(i,k)   = A(i,k) Linv(k)^T    (in place: the workgroup owns the tile; K = 128)
 //
 // The product is computed transposed (D[p][q] = C(i0+q, j0+p)) so that the 16 lanes sharing an
 // accumulator register hold 16 consecutive rows of one column: stores are 128-byte runs.
@@ -142,23 +283,24 @@ constexpr int KC = 16;            // k-depth of one LDS stage
 constexpr int LDT = 128 + 16;     // LDS row pitch (doubles): the two k-groups of a half-wave land 32 banks apart
 
 template <int MODE>
-__global__ __launch_bounds__(256) void k_gemm_nt(DevP P, double* Amat, int ld, int k, const double* Linv_all) {
+__global__ __launch_bounds__(256, 2) void k_gemm_nt(DevP P, double* Amat, int ld, int i0, int j0, int kcol, int K,
+                                                 const double* Linv) {
   __shared__ __attribute__((aligned(16))) double sA[2][KC * LDT];  // i-tile
   __shared__ __attribute__((aligned(16))) double sB[2][KC * LDT];  // j-tile
   if (!P.ws[0].active || P.ws[0].solve_failed) return;
-  const int ti = k + 1 + blockIdx.x;
-  const int tj = MODE == 0 ? k + 1 + blockIdx.y : 0;
+  const int ti = i0 + blockIdx.x;
+  const int tj = j0 + blockIdx.y;
   if (MODE == 0 && tj > ti) return;
-  const double* Ap = Amat + (long long)k * NB * ld + (long long)ti * NB;   // rows of tile i, panel columns
+  const double* Ap = Amat + (long long)kcol * ld + (long long)ti * NB;   // rows of tile i, panel columns
   const double* Bp;
   int ldb;
   double* Cp;
   if (MODE == 0) {
-    Bp = Amat + (long long)k * NB * ld + (long long)tj * NB; ldb = ld;
+    Bp = Amat + (long long)kcol * ld + (long long)tj * NB; ldb = ld;
     Cp = Amat + (long long)tj * NB * ld + (long long)ti * NB;
   } else {
-    Bp = Linv_all + (long long)k * NB * NB; ldb = NB;
-    Cp = Amat + (long long)k * NB * ld + (long long)ti * NB;
+    Bp = Linv; ldb = NB;
+    Cp = Amat + (long long)kcol * ld + (long long)ti * NB;
   }
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wr = wave >> 1, wc = wave & 1;  // wave's 64x64 quadrant: rows (i) wr, cols (j) wc
@@ -170,29 +312,28 @@ __global__ __launch_bounds__(256) void k_gemm_nt(DevP P, double* Amat, int ld, i
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
 
-  double2 ra[4], rb[4];
-  auto gload = [&](int chunk) {
-    const double* a = Ap + (long long)(chunk * KC + lcol) * ld + lrow;
-    const double* b = Bp + (long long)(chunk * KC + lcol) * ldb + lrow;
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      ra[v] = reinterpret_cast<const double2*>(a)[v];
-      rb[v] = reinterpret_cast<const double2*>(b)[v];
-    }
-  };
-  auto lstore = [&](int buf) {
-    double2* a = reinterpret_cast<double2*>(&sA[buf][lcol * LDT + lrow]);
-    double2* b = reinterpret_cast<double2*>(&sB[buf][lcol * LDT + lrow]);
-#pragma unroll
-    for (int v = 0; v < 4; ++v) { a[v] = ra[v]; b[v] = rb[v]; }
-  };
-  constexpr int nchunk = NB / KC;
-  gload(0);
-  lstore(0);
+  double2 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+#define GLOAD(chunk)                                                                        \
+  {                                                                                         \
+    const double2* a_ = reinterpret_cast<const double2*>(Ap + (long long)((chunk)*KC + lcol) * ld + lrow);  \
+    const double2* b_ = reinterpret_cast<const double2*>(Bp + (long long)((chunk)*KC + lcol) * ldb + lrow); \
+    ra0 = a_[0]; ra1 = a_[1]; ra2 = a_[2]; ra3 = a_[3];                                     \
+    rb0 = b_[0]; rb1 = b_[1]; rb2 = b_[2]; rb3 = b_[3];                                     \
+  }
+#define LSTORE(buf)                                                                         \
+  {                                                                                         \
+    double2* a_ = reinterpret_cast<double2*>(&sA[buf][lcol * LDT + lrow]);                  \
+    double2* b_ = reinterpret_cast<double2*>(&sB[buf][lcol * LDT + lrow]);                  \
+    a_[0] = ra0; a_[1] = ra1; a_[2] = ra2; a_[3] = ra3;                                     \
+    b_[0] = rb0; b_[1] = rb1; b_[2] = rb2; b_[3] = rb3;                                     \
+  }
+  const int nchunk = K / KC;
+  GLOAD(0);
+  LSTORE(0);
   __syncthreads();
   for (int c = 0; c < nchunk; ++c) {
     const int buf = c & 1;
-    if (c + 1 < nchunk) gload(c + 1);
+    if (c + 1 < nchunk) GLOAD(c + 1);
 #pragma unroll
     for (int kk = 0; kk < KC / 4; ++kk) {
       const int krow = (kk * 4 + (lane >> 4)) * LDT + (lane & 15);
@@ -207,9 +348,11 @@ __global__ __launch_bounds__(256) void k_gemm_nt(DevP P, double* Amat, int ld, i
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
     }
-    if (c + 1 < nchunk) lstore(buf ^ 1);
+    if (c + 1 < nchunk) LSTORE(buf ^ 1);
     __syncthreads();
   }
+#undef GLOAD
+#undef LSTORE
   // D[p][q]: q = lane & 15 (row i within sub-tile), p = (lane >> 4) + 4 * reg (column j within sub-tile)
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
@@ -220,7 +363,13 @@ __global__ __launch_bounds__(256) void k_gemm_nt(DevP P, double* Amat, int ld, i
         const int col = wc * 64 + a * 16 + (lane >> 4) + 4 * r;
         const int row = wr * 64 + b * 16 + (lane & 15);
         double* dst = Cp + (long long)col * ld + row;
-        if (MODE == 0) *dst -= acc[a][b][r]; else *dst = acc[a][b][r];
+        if (MODE == 0) {
+          *dst -= acc[a][b][r];
+        } else {
+          *dst = acc[a][b][r];
+          // L^T goes to the (unused) upper triangle so that the backward substitution reads columns too
+          Amat[(long long)(ti * NB + row) * ld + kcol + col] = acc[a][b][r];
+        }
       }
     }
   }
@@ -263,37 +412,40 @@ __global__ __launch_bounds__(256) void k_trsv_fwd(DevP P, const double* A, int l
   if (t < NB) rhs[i * NB + t] -= part[0][t] + part[1][t];
 }
 
-// backward step k: y_k = Linv_k^T z_k ; z_j -= L(k,j)^T y_k for every row block j < k
-__global__ __launch_bounds__(256) void k_trsv_bwd(DevP P, const double* A, int ld, int k, const double* Linv_all,
+// backward step k: y_k = Linv_k^T z_k ; z_j -= L(k,j)^T y_k for every row block j < k.  L(k,j)^T is read
+// from the upper triangle (written by the panel solve), so the access pattern mirrors the forward step.
+__global__ __launch_bounds__(256) void k_trsv_bwd(DevP P, const double* A, int ld, int k, const double* LinvT_all,
                                                   double* z, double* y) {
   __shared__ double zk[NB];
   __shared__ double yk[NB];
+  __shared__ double part[2][NB];
   if (!P.ws[0].active || P.ws[0].solve_failed) return;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const double* Linv = Linv_all + (long long)k * NB * NB;
+  const int t = threadIdx.x;
+  const double* LinvT = LinvT_all + (long long)k * NB * NB;
   if (t < NB) zk[t] = z[k * NB + t];
   __syncthreads();
-  // y_k[c] = sum_r Linv(r, c) z_k[r]; a wave reduces one column at a time (rows contiguous)
-  for (int c = wave; c < NB; c += 4) {
-    double s = Linv[c * NB + lane] * zk[lane] + Linv[c * NB + 64 + lane] * zk[64 + lane];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    if (lane == 0) yk[c] = s;
+  const int r = t & (NB - 1), h = t >> 7;
+  {
+    double s = 0.0;
+    for (int c = h * (NB / 2); c < (h + 1) * (NB / 2); ++c) s += LinvT[c * NB + r] * zk[c];
+    part[h][r] = s;
   }
+  __syncthreads();
+  if (t < NB) yk[t] = part[0][t] + part[1][t];
   __syncthreads();
   if (blockIdx.x == 0) {
     if (t < NB) y[k * NB + t] = yk[t];
     return;
   }
   const int j = blockIdx.x - 1;  // 0 .. k-1
-  const double* Lkj = A + (long long)j * NB * ld + (long long)k * NB;  // rows of block k, columns of block j
-  for (int c = wave; c < NB; c += 4) {
-    const double* col = Lkj + (long long)c * ld;
-    double s = col[lane] * yk[lane] + col[64 + lane] * yk[64 + lane];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    if (lane == 0) z[j * NB + c] -= s;
+  const double* Ujk = A + (long long)k * NB * ld + (long long)j * NB;  // rows of block j, columns of block k
+  {
+    double s = 0.0;
+    for (int c = h * (NB / 2); c < (h + 1) * (NB / 2); ++c) s += Ujk[(long long)c * ld + r] * yk[c];
+    part[h][r] = s;
   }
+  __syncthreads();
+  if (t < NB) z[j * NB + t] -= part[0][t] + part[1][t];
 }
 
 __global__ void k_store_solution(DevP P, const double* y, int n) {
@@ -308,30 +460,44 @@ __global__ void k_store_solution(DevP P, const double* y, int n) {
 hipError_t big_solve_cholesky(const DevP& P, const BigWork& W, hipStream_t s) {
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_potrf_inv), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        160 * 1024 - 256);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_potrf_inv<0xff>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
     attr_done = true;
   }
   const int n = W.n, ld = W.npad, nt = ld / NB;
-  // the number of cameras is only known on the device (P.wd); the host sized W for it
   const int ncam = n / 6;
   hipLaunchKernelGGL(k_unpack_lower, dim3((ncam * 36 + 255) / 256, ncam), dim3(256), 0, s, P, W.A, ld);
   hipLaunchKernelGGL(k_pad_init, dim3((ld + 255) / 256), dim3(256), 0, s, P, W.A, W.rhs, n, ld);
-  const size_t lds = (size_t)(NB * (NB + 1)) * 8 + 64;
-  for (int k = 0; k < nt; ++k) {
-    hipLaunchKernelGGL(k_potrf_inv, dim3(1), dim3(256), lds, s, P, W.A, ld, k, W.Linv);
-    const int rest = nt - k - 1;
-    if (rest > 0) {
-      hipLaunchKernelGGL(k_gemm_nt<1>, dim3(rest), dim3(256), 0, s, P, W.A, ld, k, W.Linv);
-      hipLaunchKernelGGL(k_gemm_nt<0>, dim3(rest, rest), dim3(256), 0, s, P, W.A, ld, k, W.Linv);
+  const size_t lds = (size_t)kPotrfTiles * kTile * 8 + 64;
+  // Two-level right-looking factorisation.  Panels of 128 columns are grouped in blocks of kOuter
+  // panels.  Inside a block a freshly factored panel only updates the block's remaining panel columns
+  // (narrow updates, K = 128); the rest of the trailing matrix is updated once per block with
+  // K = kOuter * 128, which divides the read-modify-write traffic of the trailing tiles by kOuter.
+  // (Overlapping that update with the next block's panel chain on a second stream was measured and
+  // lost 5 %: the panel kernels then queue behind 50 us trailing-update workgroups.)
+  constexpr int kOuter = 8;
+  for (int p0 = 0; p0 < nt; p0 += kOuter) {
+    const int p1 = p0 + kOuter < nt ? p0 + kOuter : nt;
+    for (int p = p0; p < p1; ++p) {
+      hipLaunchKernelGGL(k_potrf_inv<0xff>, dim3(1), dim3(256), lds, s, P, W.A, ld, p, W.Linv, W.LinvT);
+      if (nt - p - 1 > 0)
+        hipLaunchKernelGGL(k_gemm_nt<1>, dim3(nt - p - 1, 1), dim3(256), 0, s, P, W.A, ld, p + 1, 0, p * NB, NB,
+                           (const double*)(W.Linv + (long long)p * NB * NB));
+      if (p + 1 < p1)  // bring the block's remaining panel columns up to date with panel p (K = 128)
+        hipLaunchKernelGGL(k_gemm_nt<0>, dim3(nt - p - 1, p1 - p - 1), dim3(256), 0, s, P, W.A, ld, p + 1, p + 1, p * NB,
+                           NB, (const double*)nullptr);
     }
+    const int rest = nt - p1;
+    if (rest > 0)
+      hipLaunchKernelGGL(k_gemm_nt<0>, dim3(rest, rest), dim3(256), 0, s, P, W.A, ld, p1, p1, p0 * NB, (p1 - p0) * NB,
+                         (const double*)nullptr);
   }
   double* z = W.rhs + ld;
   for (int k = 0; k < nt; ++k)
     hipLaunchKernelGGL(k_trsv_fwd, dim3(nt - k), dim3(256), 0, s, P, W.A, ld, k, W.Linv, W.rhs, z);
   double* y = W.rhs;  // rhs is dead after the forward sweep
   for (int k = nt - 1; k >= 0; --k)
-    hipLaunchKernelGGL(k_trsv_bwd, dim3(k + 1), dim3(256), 0, s, P, W.A, ld, k, W.Linv, z, y);
+    hipLaunchKernelGGL(k_trsv_bwd, dim3(k + 1), dim3(256), 0, s, P, W.A, ld, k, W.LinvT, z, y);
   hipLaunchKernelGGL(k_store_solution, dim3((n + 255) / 256), dim3(256), 0, s, P, y, n);
   return hipGetLastError();
 }

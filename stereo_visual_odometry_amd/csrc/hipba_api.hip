@@ -175,13 +175,13 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   P = DevP{};
   P.n_windows = nw;
 
-  long long NP = 0, NPT = 0, NO = 0;
+  long long NP = 0, NPT = 0;
   for (int w = 0; w < nw; ++w) {
     R->meta[w].n_poses = probs[w].n_poses;
     R->meta[w].n_points = probs[w].n_points;
     R->meta[w].n_obs = probs[w].n_obs;
     R->meta[w].pose_base = (int)NP;
-    NP += probs[w].n_poses; NPT += probs[w].n_points; NO += probs[w].n_obs;
+    NP += probs[w].n_poses; NPT += probs[w].n_points;
   }
   if (NP > 0x7fffffffLL / 8 || NPT > 0x7fffffffLL / 4) { delete R; return fail(HIPBA_ERR_UNSUPPORTED, "problem too large for 32-bit block indices"); }
 

@@ -36,6 +36,7 @@ struct BigWork {
   int npad = 0;        // n rounded up to the factorisation panel width
   double* A = nullptr;     // [npad * npad] column-major, lower triangle holds S then its Cholesky factor
   double* Linv = nullptr;  // [npad/NB][NB*NB] inverses of the diagonal blocks of L
+  double* LinvT = nullptr; // the same blocks transposed (backward substitution reads them by rows)
   double* rhs = nullptr;   // [npad]
   double* pcg = nullptr;   // PCG vectors and scalars
   double* Minv = nullptr;  // [36 * ncam] block-Jacobi preconditioner
