@@ -218,7 +218,10 @@ def main():
         if os.path.exists(traffic_file):
             tr = json.load(open(traffic_file))
             for k in kernels:
-                k["traffic"] = tr.get(k["kernel"])
+                # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE doubled, WRITE_SIZE; KiB units),
+                # collected on this workload by scripts/profile_target.py + scripts/summarize_pmc.py
+                if k["kernel"] in tr and (n_p, world) == (1_000_000, 1):
+                    k["traffic"] = tr[k["kernel"]]["hbm_bytes"]
         in_loop = [k for k in kernels if k["kernel"] != "residual_jacobian"]
         dom = max(in_loop, key=lambda k: k["ms"])
         result = {

@@ -17,3 +17,6 @@ done
 for p in "${pids[@]}"; do wait $p; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT/libhipba.so build/lm_kernels.o build/dense_solver.o build/hipba_api.o
 echo "built $OUT/libhipba.so"
+# C++ host adapter demo: the ROS-free ba_test harness (plain g++, links the C ABI only)
+g++ -O2 -std=c++17 -Wall -Iinclude -I$SRC/host -o $OUT/ba_test $SRC/host/ba_test_cli.cpp -L$OUT -lhipba -Wl,-rpath,'$ORIGIN'
+echo "built $OUT/ba_test"

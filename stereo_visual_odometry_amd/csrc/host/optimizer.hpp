@@ -1,0 +1,128 @@
+// optimizer.hpp -- drop-in for the reference's VO::Optimizer (include/visual_odometry/solve/optimizer.hpp:14-19):
+// same class name, same optimize(map, K) signature, same in-place semantics, but the ceres::Problem /
+// ceres::Solve body of src/solve/optimizer.cpp:16-62 is replaced by one call into the HIP engine's C ABI.
+//
+// flattenMap / optimizeMap are templates over the map and matrix types: they only use the member names
+// the reference's own optimize() uses (frames_, features_left_, pixel, landmark_, landmarks_, pose_.data()),
+// so the same header compiles against the reference's real Map (Sophus/Eigen/OpenCV types) or against the
+// dependency-free stand-ins of vo_types.hpp.
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "hipba.h"
+
+namespace VO {
+
+struct FlatWindow {
+  std::vector<double> poses, points, uv;
+  std::vector<int32_t> obs_pose, obs_point;
+  std::vector<uint8_t> pose_const, point_const;
+  std::vector<double*> pose_storage, point_storage;  // where each block lives in the caller's map
+  hipba_problem problem{};
+};
+
+// Walks the map the way optimizer.cpp:19-52 does: frames oldest first, one residual per left feature;
+// landmarks are numbered by first appearance (the reference's unordered_set order is address dependent),
+// landmarks nobody observes come last.  first_frame_constant applies optimizer.cpp:28-36.
+template <class MapT, class KT>
+void flattenMap(const std::shared_ptr<MapT>& map, const KT& K, int camera_model, bool first_frame_constant,
+                FlatWindow* w) {
+  std::unordered_map<const void*, int32_t> index;
+  auto landmark_index = [&](double* storage) {
+    auto it = index.find(storage);
+    if (it != index.end()) return it->second;
+    const int32_t id = (int32_t)w->point_storage.size();
+    index.emplace(storage, id);
+    w->point_storage.push_back(storage);
+    w->point_const.push_back(0);
+    return id;
+  };
+  int32_t fi = 0;
+  for (const auto& frame : map->frames_) {
+    w->pose_storage.push_back(frame->pose_.data());
+    w->pose_const.push_back(first_frame_constant && fi == 0 ? 1 : 0);
+    for (const auto& feature : frame->features_left_) {
+      const int32_t li = landmark_index(feature->landmark_->pose_.data());
+      if (first_frame_constant && fi == 0) w->point_const[li] = 1;
+      w->obs_pose.push_back(fi);
+      w->obs_point.push_back(li);
+      w->uv.push_back(static_cast<double>(feature->pixel.x));  // optimizer.cpp:40-41
+      w->uv.push_back(static_cast<double>(feature->pixel.y));
+    }
+    ++fi;
+  }
+  for (const auto& landmark : map->landmarks_) landmark_index(landmark->pose_.data());
+  w->poses.resize(7 * w->pose_storage.size());
+  w->points.resize(3 * w->point_storage.size());
+  for (size_t i = 0; i < w->pose_storage.size(); ++i)
+    for (int k = 0; k < 7; ++k) w->poses[7 * i + k] = w->pose_storage[i][k];
+  for (size_t i = 0; i < w->point_storage.size(); ++i)
+    for (int k = 0; k < 3; ++k) w->points[3 * i + k] = w->point_storage[i][k];
+  hipba_problem& p = w->problem;
+  p.n_poses = (int32_t)w->pose_storage.size();
+  p.poses = w->poses.data();
+  p.pose_const = w->pose_const.data();
+  p.n_points = (int32_t)w->point_storage.size();
+  p.points = w->points.data();
+  p.point_const = w->point_const.data();
+  p.n_obs = (int64_t)w->obs_pose.size();
+  p.obs_pose = w->obs_pose.data();
+  p.obs_point = w->obs_point.data();
+  p.obs_uv = w->uv.data();
+  p.fx = K(0, 0); p.fy = K(1, 1); p.cx = K(0, 2); p.cy = K(1, 2);
+  p.camera_model = camera_model;
+}
+
+// Ceres writes through the raw pointers it was given (optimizer.cpp:21,27); so does this.
+inline void writeBack(const FlatWindow& w) {
+  for (size_t i = 0; i < w.pose_storage.size(); ++i)
+    for (int k = 0; k < 7; ++k) w.pose_storage[i][k] = w.poses[7 * i + k];
+  for (size_t i = 0; i < w.point_storage.size(); ++i)
+    for (int k = 0; k < 3; ++k) w.point_storage[i][k] = w.points[3 * i + k];
+}
+
+template <class MapT, class KT>
+hipba_summary optimizeMap(hipba_handle handle, const std::shared_ptr<MapT>& map, const KT& K, int camera_model,
+                          bool first_frame_constant, const hipba_options& options) {
+  FlatWindow w;
+  flattenMap(map, K, camera_model, first_frame_constant, &w);
+  hipba_summary summary{};
+  const int rc = hipba_solve(handle, &w.problem, &options, &summary);
+  if (rc != HIPBA_OK) throw std::runtime_error(std::string("hipba_solve: ") + hipba_last_error());
+  if (summary.termination_type != HIPBA_FAILURE) writeBack(w);
+  return summary;
+}
+
+class Optimizer {
+public:
+  Optimizer() = default;
+  Optimizer(const Optimizer&) = delete;
+  Optimizer& operator=(const Optimizer&) = delete;
+  ~Optimizer() { if (handle_) hipba_destroy(handle_); }
+
+  // reference: void Optimizer::optimize(const std::shared_ptr<Map>& map, const cv::Matx33d& K)
+  template <class MapT, class KT>
+  void optimize(const std::shared_ptr<MapT>& map, const KT& K) {
+    if (!handle_ && hipba_create(device_, &handle_) != HIPBA_OK)
+      throw std::runtime_error(std::string("hipba_create: ") + hipba_last_error());
+    hipba_options options;
+    hipba_options_default(&options);
+    options.max_num_iterations = 300;          // optimizer.cpp:58
+    options.minimizer_progress_to_stdout = 1;  // optimizer.cpp:56 (and the FullReport of line 62)
+    last_summary_ = optimizeMap(handle_, map, K, HIPBA_CAMERA_Z_FORWARD, /*first_frame_constant=*/true, options);
+  }
+
+  int device_ = 0;
+  hipba_summary last_summary_{};
+
+private:
+  hipba_handle handle_ = nullptr;
+};
+
+}  // namespace VO

@@ -311,3 +311,29 @@ def test_sharded_solve_equals_unsharded(oracle):
         assert abs(s["final_cost"] - s_ref["final_cost"]) <= 1e-9 * s_ref["final_cost"]
         assert np.abs(poses - ref.poses).max() <= 1e-8
         assert np.abs(pts - ref.points[lo:hi]).max() <= 1e-7
+
+
+def test_cpp_optimizer_adapter_through_ba_test_cli(golden):
+    """The C++ host adapter (csrc/host/optimizer.hpp) driven by the ROS-free ba_test harness on the
+    committed noisy instance: same observation count, same final cost as the golden solve."""
+    import re
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "stereo_visual_odometry_amd", "lib", "ba_test")
+    out = subprocess.run([exe, os.path.join(GOLDEN_DIR, "ba_data.txt"), "--noisy",
+                          os.path.join(GOLDEN_DIR, "ba_data_noisy.txt")], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert "frames 5 landmarks 25 observations 27" in out.stdout
+    assert "Total error (ground truth): 0" in out.stdout
+    final = float(re.search(r"final cost ([0-9.eE+-]+)", out.stdout).group(1))
+    want = golden["cases"][0]["solve_analytic"]["summary"]["final_cost"]
+    assert abs(final - want) <= 1e-6 * max(want, 1e-9) + 1e-12
+    total = float(re.search(r"^Total error: ([0-9.eE+-]+)", out.stdout, re.M).group(1))
+    assert total < 1e-2
+    # production semantics through the same adapter
+    out = subprocess.run([exe, os.path.join(GOLDEN_DIR, "ba_data.txt"), "--noisy",
+                          os.path.join(GOLDEN_DIR, "ba_data_noisy.txt"), "--production"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    final = float(re.search(r"final cost ([0-9.eE+-]+)", out.stdout).group(1))
+    want = golden["cases"][1]["solve_analytic"]["summary"]["final_cost"]
+    assert abs(final - want) <= 1e-6 * want

@@ -123,3 +123,11 @@ def test_shards_partition_landmarks_and_observations():
             assert sh.obs_point.min() >= 0 and sh.obs_point.max() < hi - lo
             np.testing.assert_array_equal(sh.points, b.points[lo:hi])
         assert n_obs == b.obs_pose.shape[0] and np.all(covered == 1)
+
+
+def test_cpp_harness_is_built_and_links_the_c_abi():
+    import subprocess
+    exe = os.path.join(ROOT, "stereo_visual_odometry_amd", "lib", "ba_test")
+    assert os.path.exists(exe), "run ./build.sh"
+    out = subprocess.run([exe, "--help"], capture_output=True, text=True)
+    assert out.returncode == 0 and "usage: ba_test" in out.stdout
