@@ -109,6 +109,12 @@ struct DevP {
   const long long* pp_obs_start;  // [n_pm_points+1]
   const BlockDesc* blocks;
   const unsigned short* pairs;    // low byte = lane i, high byte = lane j, slot_i <= slot_j
+  // staged accumulation of the reduced matrix (one large window): slot of every pair in a buffer ordered
+  // by destination block, and the CSR of that order; null when fp64 atomics are used instead
+  const unsigned int* pair_slot;
+  const long long* dest_start;    // [n_dest + 1]
+  double* stage;                  // [36 * n_pairs]
+  long long n_dest;
   const WinDesc* wd;
   WinState* ws;
   // work arrays

@@ -374,6 +374,36 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   const int n_blk_cc = (int)blocks.size() - n_blk_pm - n_blk_vc;
   const int n_blocks = (int)blocks.size();
 
+  // ---- staged accumulation order (one large window): pairs sorted by destination block ----------------
+  // fp64 atomics into S run at ~1 TB/s of added bytes; beyond a few million 6x6 products it is faster to
+  // store every product once and sum per destination in a second pass.
+  std::vector<unsigned int> pair_slot;
+  std::vector<long long> dest_start;
+  long long n_dest = 0;
+  const bool staged = nw == 1 && max_ncam > 20 && pairs.size() >= (size_t)2000000 && pairs.size() < 0xffffffffull &&
+                      pairs.size() * 288ull <= 64ull << 30;
+  if (staged) {
+    const int ncam = wd[0].ncam;
+    n_dest = (long long)ncam * (ncam + 1) / 2;
+    dest_start.assign(n_dest + 1, 0);
+    std::vector<long long> dest_of(pairs.size());
+    for (const BlockDesc& d : blocks) {
+      if (d.kind != 0) continue;
+      for (int q = 0; q < d.n_pairs; ++q) {
+        const unsigned short pr = pairs[d.pair_begin + q];
+        const int si = pose_gslot[obs_pose[d.obs_begin + (pr & 0xff)]] - wd[0].cam_base;
+        const int sj = pose_gslot[obs_pose[d.obs_begin + (pr >> 8)]] - wd[0].cam_base;
+        const long long dst = tri_index(si, sj, ncam);
+        dest_of[d.pair_begin + q] = dst;
+        dest_start[dst + 1]++;
+      }
+    }
+    for (long long i = 0; i < n_dest; ++i) dest_start[i + 1] += dest_start[i];
+    std::vector<long long> cur(dest_start.begin(), dest_start.end() - 1);
+    pair_slot.resize(pairs.size());
+    for (size_t g = 0; g < pairs.size(); ++g) pair_slot[g] = (unsigned int)(cur[dest_of[g]]++);
+  }
+
   // ---- camera-major lists ------------------------------------------------------------------------
   std::vector<long long> cm_start(n_slots + 1, 0);
   for (long long o = 0; o < n_act_obs; ++o) {
@@ -425,6 +455,7 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   long long *d_cm_start, *d_pp_start;
   double *d_cm_uv, *d_obs_uv;
   BlockDesc* d_blocks; unsigned short* d_pairs; WinDesc* d_wd;
+  unsigned int* d_pair_slot = nullptr; long long* d_dest_start = nullptr;
   up.add(&P.poses[0], poses.size());
   up.add(&P.points[0], points.size());
   up.add(&d_pose_window, std::max<size_t>(pose_window.size(), 1));
@@ -440,6 +471,7 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   up.add(&d_blocks, std::max<size_t>(blocks.size(), 1));
   up.add(&d_pairs, std::max<size_t>(pairs.size(), 1));
   up.add(&d_wd, wd.size());
+  if (staged) { up.add(&d_pair_slot, pair_slot.size()); up.add(&d_dest_start, dest_start.size()); }
   const size_t upload_bytes = up.total;
   ArenaPlan work = up;  // continues after the uploaded region
   work.items.clear();
@@ -463,6 +495,7 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   work.add(&P.wsum, (size_t)8 * nw);
   work.add(&P.log, (size_t)std::max(log_cap, 1) * nw);
   work.add(&R->d_count, 4);
+  if (staged) work.add(&P.stage, 36 * pairs.size());
   char* big_base_dummy = nullptr;
   size_t big_bytes = 0;
   if (6 * max_ncam > kSmallMaxN) {
@@ -497,6 +530,8 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   P.cm_start = d_cm_start; P.cm_dp = d_cm_dp; P.cm_uv = d_cm_uv;
   P.obs_pose = d_obs_pose; P.obs_dp = d_obs_dp; P.obs_uv = d_obs_uv; P.pp_obs_start = d_pp_start;
   P.blocks = d_blocks; P.pairs = d_pairs; P.wd = d_wd;
+  P.pair_slot = d_pair_slot; P.dest_start = d_dest_start; P.n_dest = n_dest;
+  if (!staged) P.stage = nullptr;
 
   char* st = static_cast<char*>(h->staging);
   auto stage = [&](const void* dev_ptr, const void* src, size_t bytes) {
@@ -517,6 +552,10 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   stage(d_blocks, blocks.data(), blocks.size() * sizeof(BlockDesc));
   stage(d_pairs, pairs.data(), pairs.size() * 2);
   stage(d_wd, wd.data(), wd.size() * sizeof(WinDesc));
+  if (staged) {
+    stage(d_pair_slot, pair_slot.data(), pair_slot.size() * 4);
+    stage(d_dest_start, dest_start.data(), dest_start.size() * 8);
+  }
   hipStream_t s = h->stream;
   hipError_t e = hipMemcpyAsync(R->arena, h->staging, upload_bytes, hipMemcpyHostToDevice, s);
   if (e == hipSuccess) e = hipMemcpyAsync(P.poses[1], P.poses[0], poses.size() * 8, hipMemcpyDeviceToDevice, s);

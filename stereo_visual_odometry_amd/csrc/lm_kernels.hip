@@ -317,8 +317,13 @@ __global__ void k_init_reduced(DevP P, LmParams lm, int owner) {
 constexpr int kPairGroup = 12;
 constexpr int kPairGroups = kBlock / kPairGroup;  // 21
 
-template <bool LDS_ACC>
+// MODE 0: fp64 atomics straight into S.  MODE 1 (LDS_ACC): the window's whole packed S and b fit in LDS;
+// accumulate there and flush once.  MODE 2 (staged): every 6x6 product is written with plain stores to its
+// precomputed slot of a staging buffer ordered by destination block; k_reduce_staged sums the slots
+// (no atomics on S, fixed summation order).
+template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_point_schur(DevP P, LmParams lm) {
+  constexpr bool LDS_ACC = MODE == 1;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* sYW = smem;                         // [kBlock][36]: Y (18) then W (18); phase 1 aliases 9 words/lane
   int* sslot = reinterpret_cast<int*>(smem + kBlock * 36);  // [kBlock] local slot or -1
@@ -438,12 +443,21 @@ __global__ __launch_bounds__(kBlock) void k_point_schur(DevP P, LmParams lm) {
       const double* Yi = sYW + 36 * i;
       const double* Wj = sYW + 36 * j + 18 + 3 * bcol;
       const double w0 = Wj[0], w1 = Wj[1], w2 = Wj[2];
-      double* dst = (LDS_ACC ? accS : P.S + wd.S_off) + 36ll * tri_index(si, sj, wd.ncam);
+      if (MODE == 2) {
+        double* dst = P.stage + 36ll * P.pair_slot[d.pair_begin + q];
 #pragma unroll
-      for (int m = 0; m < 3; ++m) {
-        const int a = a0 + 2 * m;
-        const double v = Yi[3 * a] * w0 + Yi[3 * a + 1] * w1 + Yi[3 * a + 2] * w2;
-        atomic_add_f64(dst + 6 * a + bcol, -v);
+        for (int m = 0; m < 3; ++m) {
+          const int a = a0 + 2 * m;
+          dst[6 * a + bcol] = -(Yi[3 * a] * w0 + Yi[3 * a + 1] * w1 + Yi[3 * a + 2] * w2);
+        }
+      } else {
+        double* dst = (LDS_ACC ? accS : P.S + wd.S_off) + 36ll * tri_index(si, sj, wd.ncam);
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+          const int a = a0 + 2 * m;
+          const double v = Yi[3 * a] * w0 + Yi[3 * a + 1] * w1 + Yi[3 * a + 2] * w2;
+          atomic_add_f64(dst + 6 * a + bcol, -v);
+        }
       }
     }
   }
@@ -468,6 +482,29 @@ __global__ __launch_bounds__(kBlock) void k_point_schur(DevP P, LmParams lm) {
       const double v = accS[nS + i];
       if (v != 0.0) atomic_add_f64(bg + i, v);
     }
+  }
+}
+
+// staged mode: S(block d) += sum of its staged 6x6 contributions; 36 lanes per destination block,
+// seven destinations in flight per workgroup, contributions of one block are contiguous
+__global__ __launch_bounds__(kBlock) void k_reduce_staged(DevP P, long long n_dest) {
+  if (!P.ws[0].active) return;
+  const int grp = threadIdx.x / 36, e = threadIdx.x - grp * 36;
+  if (grp >= 7) return;
+  double* S = P.S + P.wd[0].S_off;
+  for (long long d = (long long)blockIdx.x * 7 + grp; d < n_dest; d += (long long)gridDim.x * 7) {
+    const long long s0 = P.dest_start[d], s1 = P.dest_start[d + 1];
+    if (s1 == s0) continue;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    long long s = s0;
+    for (; s + 4 <= s1; s += 4) {
+      a0 += P.stage[36 * s + e];
+      a1 += P.stage[36 * (s + 1) + e];
+      a2 += P.stage[36 * (s + 2) + e];
+      a3 += P.stage[36 * (s + 3) + e];
+    }
+    for (; s < s1; ++s) a0 += P.stage[36 * s + e];
+    S[36 * d + e] += (a0 + a1) + (a2 + a3);
   }
 }
 
@@ -1024,17 +1061,26 @@ hipError_t launch_point_schur(const DevP& P, const LmParams& lm, int lds_acc_nca
   if (P.n_blk_pm <= 0) return hipSuccess;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_point_schur<false>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_point_schur<true>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_point_schur<0>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_point_schur<1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_point_schur<2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   const size_t lds = schur_lds_bytes(lds_acc_ncam);
-  if (lds_acc_ncam > 0)
-    hipLaunchKernelGGL(k_point_schur<true>, dim3(P.n_blk_pm), dim3(kBlock), lds, s, P, lm);
-  else
-    hipLaunchKernelGGL(k_point_schur<false>, dim3(P.n_blk_pm), dim3(kBlock), lds, s, P, lm);
+  if (P.stage) {
+    hipLaunchKernelGGL(k_point_schur<2>, dim3(P.n_blk_pm), dim3(kBlock), lds, s, P, lm);
+    const long long n_dest = P.n_dest;
+    const long long want = (n_dest + 6) / 7;
+    const unsigned grid = (unsigned)(want < 16384 ? want : 16384);
+    hipLaunchKernelGGL(k_reduce_staged, dim3(grid), dim3(kBlock), 0, s, P, n_dest);
+  } else if (lds_acc_ncam > 0) {
+    hipLaunchKernelGGL(k_point_schur<1>, dim3(P.n_blk_pm), dim3(kBlock), lds, s, P, lm);
+  } else {
+    hipLaunchKernelGGL(k_point_schur<0>, dim3(P.n_blk_pm), dim3(kBlock), lds, s, P, lm);
+  }
   return hipGetLastError();
 }
 

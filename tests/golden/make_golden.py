@@ -71,6 +71,12 @@ def main():
         case("ba_data_production_semantics", p_prod, oracle.LOSS_NONE, 1.0, 300),
         case("zforward_3pose_20point_production", p_z, oracle.LOSS_NONE, 1.0, 300),
     ]
+    # the same noisy instance in scene-file order, for the C++ harness (ba_test --noisy)
+    with open(os.path.join(HERE, "ba_data_noisy.txt"), "w") as f:
+        for fr in noisy.frames_:
+            f.write("pose " + " ".join(repr(float(x)) for x in fr.pose_) + "\n")
+        for lm in noisy.landmarks_:
+            f.write("landmark " + " ".join(repr(float(x)) for x in lm.pose_) + "\n")
     doc = {"ground_truth": dump_problem(gt), "cases": cases}
     with open(os.path.join(HERE, "ba_golden.json"), "w") as f:
         json.dump(doc, f)

@@ -337,3 +337,20 @@ def test_cpp_optimizer_adapter_through_ba_test_cli(golden):
     final = float(re.search(r"final cost ([0-9.eE+-]+)", out.stdout).group(1))
     want = golden["cases"][1]["solve_analytic"]["summary"]["final_cost"]
     assert abs(final - want) <= 1e-6 * want
+
+
+def test_staged_schur_accumulation_matches_oracle(solver, oracle):
+    # >= 2M 6x6 products switch the reduced-matrix accumulation from atomics to store-then-sum
+    prob, _, _ = scenes.bal_scale(seed=21, grid=(10, 10), n_points=60000, depth_lo=5.0, depth_hi=30.0)
+    g = prob.copy()
+    s = solver.solve(g, hipba.default_options(max_num_iterations=6))
+    o = to_oracle(oracle, prob)
+    so, oits = oracle.solve(o, oracle.default_options(max_num_iterations=6, jacobian_mode=oracle.JAC_ANALYTIC, num_threads=8))
+    assert s["termination_type"] == so["termination_type"]
+    assert abs(s["final_cost"] - so["final_cost"]) <= RTOL_COST * so["final_cost"]
+    assert np.abs(g.poses - o.poses).max() <= ATOL_STATE and np.abs(g.points - o.points).max() <= ATOL_STATE
+    assert_logs_match(s["iterations"], oits)
+    # S is summed in a fixed order on this path; only the right-hand side still uses atomics
+    g2 = prob.copy()
+    solver.solve(g2, hipba.default_options(max_num_iterations=6))
+    assert np.abs(g.poses - g2.poses).max() <= 1e-11
