@@ -24,18 +24,32 @@ namespace hipba {
 constexpr int kBlock = 256;        // threads per workgroup in the observation kernels
 constexpr int kPartialStride = 4;  // doubles of per-block partial results
 constexpr int kSmallMaxN = 192;    // largest reduced system solved inside one workgroup's LDS
+constexpr int kLdsSMaxCam = 21;    // most poses for which the packed reduced matrix is accumulated in LDS
+constexpr int kSmallBlk = 37;      // LDS stride of a 6x6 block in that solver (odd: neighbouring blocks fall on different banks)
 
 // modes of the per-window kernels (see lm_kernels.hip)
 enum { kFused = 0, kReduce = 1, kDecide = 2 };
 
 struct BlockDesc {
   long long obs_begin;   // first observation (index into obs_* arrays)
-  long long pair_begin;  // first entry of this block's pair list
+  long long pair_begin;  // first entry of this block's pair list (a multiple of 8)
+  long long run_begin;   // first entry of this block's run list (a multiple of 2)
   int n_obs;             // <= kBlock
   int n_pairs;
+  int n_runs;
   int window;
   int kind;              // 0 = PM, 1 = VC, 2 = CC
+  int pad;
 };
+
+// a run: consecutive entries of a block's pair list that go to the same 6x6 block of the reduced matrix
+struct RunDesc {
+  unsigned int first_count;  // (offset of the first pair in the block's list << 8) | number of pairs
+  unsigned int dest;         // packed upper block-triangular index within the window
+};
+constexpr int kRunMax = 8;                        // pairs per run
+constexpr unsigned short kPairPad = 0x00ff;       // filler entry of a pair list (lane 255 before lane 0: never a pair)
+constexpr int kLdsPairs = 4096, kLdsRuns = 1024;  // a block's lists are staged in LDS up to these sizes
 
 struct WinDesc {
   CameraK K;
@@ -109,6 +123,7 @@ struct DevP {
   const long long* pp_obs_start;  // [n_pm_points+1]
   const BlockDesc* blocks;
   const unsigned short* pairs;    // low byte = lane i, high byte = lane j, slot_i <= slot_j
+  const RunDesc* runs;            // pair lists cut into runs of one destination (absent in staged mode)
   // staged accumulation of the reduced matrix (one large window): slot of every pair in a buffer ordered
   // by destination block, and the CSR of that order; null when fp64 atomics are used instead
   const unsigned int* pair_slot;

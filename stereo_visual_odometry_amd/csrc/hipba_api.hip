@@ -16,6 +16,7 @@
 #include <cstring>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "hipba_internal.hpp"
@@ -82,6 +83,7 @@ struct hipba_device_problem_s {
   double* points0 = nullptr;
   int* d_count = nullptr;
   int max_ncam = 0;
+  int max_pm_blocks = 0;      // most PM blocks in one window
   int n_blocks = 0;
   long long S_doubles = 0;
   BigWork big;
@@ -89,6 +91,13 @@ struct hipba_device_problem_s {
 };
 
 namespace {
+
+// workgroups per window in the small-window landmark elimination: enough to fill the chip, few enough
+// that the per-workgroup flush of the LDS accumulators stays a small part of the work
+int schur_parts_for(int n_windows, int max_pm_blocks) {
+  const int want = (4096 + n_windows - 1) / std::max(1, n_windows);
+  return std::max(1, std::min(want, max_pm_blocks));
+}
 
 // ---- arena planning ----------------------------------------------------------------------------
 struct ArenaPlan {
@@ -321,6 +330,7 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
     while (pp < wd[w].pp_end) {
       BlockDesc d{};
       d.obs_begin = pp_start[pp];
+      while (pairs.size() % 8) pairs.push_back(kPairPad);  // 16-byte aligned lists: blocks load them as uint4
       d.pair_begin = (long long)pairs.size();
       d.window = w;
       d.kind = 0;
@@ -343,6 +353,7 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
     }
     wd[w].pm_blk_end = (int)blocks.size();
   }
+  for (int i = 0; i < 8; ++i) pairs.push_back(kPairPad);    // whole-uint4 reads of the last list stay inside
   const int n_blk_pm = (int)blocks.size();
   {
     long long cur = n_pm_obs;
@@ -401,7 +412,100 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
     for (long long i = 0; i < n_dest; ++i) dest_start[i + 1] += dest_start[i];
     std::vector<long long> cur(dest_start.begin(), dest_start.end() - 1);
     pair_slot.resize(pairs.size());
-    for (size_t g = 0; g < pairs.size(); ++g) pair_slot[g] = (unsigned int)(cur[dest_of[g]]++);
+    for (const BlockDesc& d : blocks) {
+      if (d.kind != 0) continue;
+      for (int q = 0; q < d.n_pairs; ++q) pair_slot[d.pair_begin + q] = (unsigned int)(cur[dest_of[d.pair_begin + q]]++);
+    }
+  }
+
+  // ---- atomic / LDS accumulation: each block's pair list grouped by destination block and cut into runs
+  // of at most kRunMax pairs with one destination; a lane group sums a run in registers and adds it to
+  // the reduced matrix once ------------------------------------------------------------------------
+  std::vector<RunDesc> runs;
+  const long long n_dest_max = (long long)max_ncam * (max_ncam + 1) / 2;
+  if (!staged && n_blk_pm > 0) {
+    const int n_thr = (int)std::min<size_t>(std::max(1u, std::min(16u, std::thread::hardware_concurrency())),
+                                            1 + pairs.size() / 1000000);
+    std::vector<std::vector<RunDesc>> runs_of(n_thr);
+    std::vector<std::vector<int>> nruns_of(n_thr);
+    auto group_range = [&](int ti, int b0, int b1) {
+      // counting sort over the destinations a block touches, in order of first appearance
+      std::vector<int> count, touched, key;
+      std::vector<std::pair<long long, int>> keyed;   // fallback when a count array would be too large
+      const bool counting = n_dest_max <= (1ll << 22);
+      if (counting) count.assign(n_dest_max, 0);
+      std::vector<unsigned short> out;
+      for (int bi = b0; bi < b1; ++bi) {
+        const BlockDesc& d = blocks[bi];
+        const int ncam = wd[d.window].ncam, cam_base = wd[d.window].cam_base;
+        int nr = 0;
+        auto emit = [&](long long dest, int first, int n) {
+          for (int o = 0; o < n; o += kRunMax) {
+            runs_of[ti].push_back(RunDesc{((unsigned)(first + o) << 8) | (unsigned)std::min(kRunMax, n - o), (unsigned)dest});
+            ++nr;
+          }
+        };
+        auto dest_of_pair = [&](unsigned short pr) {
+          const int si = pose_gslot[obs_pose[d.obs_begin + (pr & 0xff)]] - cam_base;
+          const int sj = pose_gslot[obs_pose[d.obs_begin + (pr >> 8)]] - cam_base;
+          return tri_index(si, sj, ncam);
+        };
+        if (counting) {
+          key.resize(d.n_pairs);
+          out.resize(d.n_pairs);
+          touched.clear();
+          for (int q = 0; q < d.n_pairs; ++q) {
+            const int kq = (int)dest_of_pair(pairs[d.pair_begin + q]);
+            key[q] = kq;
+            if (count[kq]++ == 0) touched.push_back(kq);
+          }
+          int run = 0;
+          for (int kq : touched) {
+            const int c = count[kq];
+            emit(kq, run, c);
+            count[kq] = run;
+            run += c;
+          }
+          for (int q = 0; q < d.n_pairs; ++q) out[count[key[q]]++] = pairs[d.pair_begin + q];
+          for (int kq : touched) count[kq] = 0;
+          std::copy(out.begin(), out.end(), pairs.begin() + d.pair_begin);
+        } else {
+          keyed.resize(d.n_pairs);
+          for (int q = 0; q < d.n_pairs; ++q) keyed[q] = {dest_of_pair(pairs[d.pair_begin + q]), pairs[d.pair_begin + q]};
+          std::sort(keyed.begin(), keyed.end());
+          for (int q = 0, q0 = 0; q <= d.n_pairs; ++q) {
+            if (q < d.n_pairs) pairs[d.pair_begin + q] = (unsigned short)keyed[q].second;
+            if (q == d.n_pairs || keyed[q].first != keyed[q0].first) {
+              if (q > q0) emit(keyed[q0].first, q0, q - q0);
+              q0 = q;
+            }
+          }
+        }
+        nruns_of[ti].push_back(nr);
+      }
+    };
+    auto lo = [&](int i) { return (int)((long long)n_blk_pm * i / n_thr); };
+    if (n_thr <= 1) {
+      group_range(0, 0, n_blk_pm);
+    } else {
+      std::vector<std::thread> pool;
+      for (int i = 0; i < n_thr; ++i) pool.emplace_back(group_range, i, lo(i), lo(i + 1));
+      for (auto& th : pool) th.join();
+    }
+    // splice the per-thread run lists, every block's list starting on a 16-byte boundary
+    for (int i = 0; i < n_thr; ++i) {
+      size_t src = 0;
+      for (int bi = lo(i); bi < lo(i + 1); ++bi) {
+        const int nr = nruns_of[i][bi - lo(i)];
+        if (runs.size() % 2) runs.push_back(RunDesc{0, 0});
+        blocks[bi].run_begin = (long long)runs.size();
+        blocks[bi].n_runs = nr;
+        runs.insert(runs.end(), runs_of[i].begin() + src, runs_of[i].begin() + src + nr);
+        src += nr;
+      }
+    }
+    runs.push_back(RunDesc{0, 0});
+    runs.push_back(RunDesc{0, 0});
   }
 
   // ---- camera-major lists ------------------------------------------------------------------------
@@ -448,13 +552,15 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   P.n_pm_obs = n_pm_obs; P.n_act_obs = n_act_obs; P.n_all_obs = n_all;
   P.n_blk_pm = n_blk_pm; P.n_blk_vc = n_blk_vc; P.n_blk_cc = n_blk_cc;
   P.log_cap = log_cap;
-  R->max_ncam = max_ncam; R->n_blocks = n_blocks; R->S_doubles = S_doubles;
+  R->max_ncam = max_ncam; R->n_blocks = n_blocks;
+  R->S_doubles = S_doubles;
+  for (int w = 0; w < nw; ++w) R->max_pm_blocks = std::max(R->max_pm_blocks, wd[w].pm_blk_end - wd[w].pm_blk_begin);
 
   ArenaPlan up;  // uploaded region (one host->device copy)
   int *d_pose_window, *d_pose_gslot, *d_slot_pose, *d_cm_dp, *d_obs_pose, *d_obs_dp;
   long long *d_cm_start, *d_pp_start;
   double *d_cm_uv, *d_obs_uv;
-  BlockDesc* d_blocks; unsigned short* d_pairs; WinDesc* d_wd;
+  BlockDesc* d_blocks; unsigned short* d_pairs; WinDesc* d_wd; RunDesc* d_runs;
   unsigned int* d_pair_slot = nullptr; long long* d_dest_start = nullptr;
   up.add(&P.poses[0], poses.size());
   up.add(&P.points[0], points.size());
@@ -471,6 +577,7 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   up.add(&d_blocks, std::max<size_t>(blocks.size(), 1));
   up.add(&d_pairs, std::max<size_t>(pairs.size(), 1));
   up.add(&d_wd, wd.size());
+  up.add(&d_runs, std::max<size_t>(runs.size(), 1));
   if (staged) { up.add(&d_pair_slot, pair_slot.size()); up.add(&d_dest_start, dest_start.size()); }
   const size_t upload_bytes = up.total;
   ArenaPlan work = up;  // continues after the uploaded region
@@ -529,7 +636,7 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   P.pose_window = d_pose_window; P.pose_gslot = d_pose_gslot; P.slot_pose = d_slot_pose;
   P.cm_start = d_cm_start; P.cm_dp = d_cm_dp; P.cm_uv = d_cm_uv;
   P.obs_pose = d_obs_pose; P.obs_dp = d_obs_dp; P.obs_uv = d_obs_uv; P.pp_obs_start = d_pp_start;
-  P.blocks = d_blocks; P.pairs = d_pairs; P.wd = d_wd;
+  P.blocks = d_blocks; P.pairs = d_pairs; P.wd = d_wd; P.runs = d_runs;
   P.pair_slot = d_pair_slot; P.dest_start = d_dest_start; P.n_dest = n_dest;
   if (!staged) P.stage = nullptr;
 
@@ -552,6 +659,7 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   stage(d_blocks, blocks.data(), blocks.size() * sizeof(BlockDesc));
   stage(d_pairs, pairs.data(), pairs.size() * 2);
   stage(d_wd, wd.data(), wd.size() * sizeof(WinDesc));
+  stage(d_runs, runs.data(), runs.size() * sizeof(RunDesc));
   if (staged) {
     stage(d_pair_slot, pair_slot.data(), pair_slot.size() * 4);
     stage(d_dest_start, dest_start.data(), dest_start.size() * 8);
@@ -597,9 +705,9 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
   int solver = o.linear_solver;
   if (small) solver = HIPBA_LINEAR_DENSE_CHOLESKY;
   else if (solver == HIPBA_LINEAR_AUTO) solver = HIPBA_LINEAR_DENSE_CHOLESKY;
-  // LDS accumulation of the reduced matrix pays when a window's packed S is small
-  int lds_acc_ncam = 0;
-  if (R->max_ncam > 0 && R->max_ncam <= 20 && !sharded) lds_acc_ncam = R->max_ncam;
+  // windows the in-LDS solver takes also accumulate b (and a small enough S) in LDS
+  const int small_ncam = small ? R->max_ncam : 0;
+  const int schur_parts = schur_parts_for(P.n_windows, R->max_pm_blocks);
 
   auto allreduce = [&](double* buf, size_t n, int op) -> int {
     if (!sharded) return 0;
@@ -635,7 +743,7 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
     }
     if (R->S_doubles) HIPBA_HIP(hipMemsetAsync(P.S, 0, sizeof(double) * (size_t)R->S_doubles, s));
     HIPBA_HIP(launch_init_reduced(P, lm, owner, s));
-    HIPBA_HIP(launch_point_schur(P, lm, lds_acc_ncam, s));
+    HIPBA_HIP(launch_point_schur(P, lm, small_ncam, schur_parts, s));
     if (sharded) {
       if (R->S_doubles) AR(P.S, (size_t)R->S_doubles, HIPBA_REDUCE_SUM);
       if (P.n_act_poses) AR(P.b, 6 * (size_t)P.n_act_poses, HIPBA_REDUCE_SUM);
@@ -1012,7 +1120,8 @@ int hipba_time_kernel(hipba_handle h, hipba_device_problem dp, const hipba_optio
   const int n_act_blk = P.n_blk_pm + P.n_blk_vc;
   const int max_n = 6 * dp->max_ncam;
   const bool small = max_n <= kSmallMaxN;
-  int lds_acc_ncam = (dp->max_ncam > 0 && dp->max_ncam <= 20) ? dp->max_ncam : 0;
+  const int small_ncam = small ? dp->max_ncam : 0;
+  const int schur_parts = schur_parts_for(P.n_windows, dp->max_pm_blocks);
   // bring the work arrays to the state of a first iteration (parameters are not modified)
   auto prepare = [&]() -> int {
     HIPBA_HIP(launch_cost(P, lm, 0, n_act_blk, 0, 1, false, s));
@@ -1023,7 +1132,7 @@ int hipba_time_kernel(hipba_handle h, hipba_device_problem dp, const hipba_optio
     HIPBA_HIP(launch_point_colnorm(P, lm, s));
     if (dp->S_doubles) HIPBA_HIP(hipMemsetAsync(P.S, 0, sizeof(double) * (size_t)dp->S_doubles, s));
     HIPBA_HIP(launch_init_reduced(P, lm, 1, s));
-    HIPBA_HIP(launch_point_schur(P, lm, lds_acc_ncam, s));
+    HIPBA_HIP(launch_point_schur(P, lm, small_ncam, schur_parts, s));
     return HIPBA_OK;
   };
   auto solve_once = [&]() -> int {
@@ -1058,7 +1167,7 @@ int hipba_time_kernel(hipba_handle h, hipba_device_problem dp, const hipba_optio
                                            P.obs_uv, jbuf, jbuf + 2 * nj, jbuf + 14 * nj, nullptr, nullptr, s));
         break;
       case HIPBA_KERNEL_CAMERA_BLOCKS: HIPBA_HIP(launch_camera_blocks(P, lm, 1, s)); break;
-      case HIPBA_KERNEL_POINT_SCHUR: HIPBA_HIP(launch_point_schur(P, lm, lds_acc_ncam, s)); break;
+      case HIPBA_KERNEL_POINT_SCHUR: HIPBA_HIP(launch_point_schur(P, lm, small_ncam, schur_parts, s)); break;
       case HIPBA_KERNEL_BACKSUB: HIPBA_HIP(launch_backsub(P, lm, s)); break;
       case HIPBA_KERNEL_REDUCED_SOLVE: return solve_once();
       default: return fail(HIPBA_ERR_INVALID_ARGUMENT, "kernel %d cannot be timed on a resident problem", kernel);
@@ -1072,7 +1181,7 @@ int hipba_time_kernel(hipba_handle h, hipba_device_problem dp, const hipba_optio
       for (int i = 0; i < repeats && !rc; ++i) {
         if (dp->S_doubles) HIPBA_HIP(hipMemsetAsync(P.S, 0, sizeof(double) * (size_t)dp->S_doubles, s));
         HIPBA_HIP(launch_init_reduced(P, lm, 1, s));
-        HIPBA_HIP(launch_point_schur(P, lm, lds_acc_ncam, s));
+        HIPBA_HIP(launch_point_schur(P, lm, small_ncam, schur_parts, s));
         HIPBA_HIP(hipEventRecord(e0, s));
         rc = one();
         HIPBA_HIP(hipEventRecord(e1, s));

@@ -314,163 +314,302 @@ __global__ void k_init_reduced(DevP P, LmParams lm, int owner) {
 //          bytes of that block (S is stored block-major for exactly this reason).
 // LDS_ACC: the window's whole packed S and b fit in LDS; accumulate there and flush once.
 // ------------------------------------------------------------------------------------------
+#ifdef HIPBA_PHASE_TIMING
+// development aid: 100 MHz timestamps of workgroup phases, read back by hipba_debug_ticks
+__device__ unsigned long long g_ticks[8 * 4096];
+#define HIPBA_TICK(i) \
+  if (threadIdx.x == 0 && blockIdx.x < 4096) g_ticks[8 * blockIdx.x + (i)] = wall_clock64()
+#define HIPBA_CYCLES(i) \
+  if (threadIdx.x == 0 && blockIdx.x < 4096) g_ticks[8 * blockIdx.x + (i)] = clock64()
+#else
+#define HIPBA_TICK(i)
+#define HIPBA_CYCLES(i)
+#endif
+
 constexpr int kPairGroup = 12;
 constexpr int kPairGroups = kBlock / kPairGroup;  // 21
+constexpr int kYW = 37;  // LDS doubles per lane for Y (18) and W (18); odd, so lanes fall on different banks
 
-// MODE 0: fp64 atomics straight into S.  MODE 1 (LDS_ACC): the window's whole packed S and b fit in LDS;
-// accumulate there and flush once.  MODE 2 (staged): every 6x6 product is written with plain stores to its
-// precomputed slot of a staging buffer ordered by destination block; k_reduce_staged sums the slots
-// (no atomics on S, fixed summation order).
+// Pair products of one block: a lane group takes whole runs (same destination), sums each in registers
+// and adds it to the reduced matrix once.  WIDE: twelve lanes per product, three outputs each, the three
+// atomics of a group covering 96 contiguous bytes of the destination block (for S in HBM).  Otherwise two
+// lanes per product, lane h owning columns 3h..3h+2 (for S in LDS: half the LDS bytes read per multiply-add).
+template <bool WIDE>
+__device__ __forceinline__ void pair_products(const unsigned short* pairs, const RunDesc* runs, int n_runs,
+                                              const double* sYW, double* Sbase, int t) {
+  if (WIDE) {
+    const int grp = t / kPairGroup, k = t - grp * kPairGroup;
+    if (grp >= kPairGroups) return;
+    const int bcol = k % 6, a0 = k / 6;
+    for (int r = grp; r < n_runs; r += kPairGroups) {
+      const RunDesc rd = runs[r];
+      const int off = rd.first_count >> 8, cnt = rd.first_count & 0xff;
+      unsigned short pr[kRunMax];
+#pragma unroll
+      for (int q = 0; q < kRunMax; ++q) pr[q] = pairs[off + q];
+      double acc[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+      for (int q = 0; q < kRunMax; ++q) {
+        if (q < cnt) {
+          const int i = pr[q] & 0xff, j = pr[q] >> 8;
+          const double* Yi = sYW + kYW * i;
+          const double* Wj = sYW + kYW * j + 18 + 3 * bcol;
+          const double w0 = Wj[0], w1 = Wj[1], w2 = Wj[2];
+#pragma unroll
+          for (int m = 0; m < 3; ++m) {
+            const int a = a0 + 2 * m;
+            acc[m] += Yi[3 * a] * w0 + Yi[3 * a + 1] * w1 + Yi[3 * a + 2] * w2;
+          }
+        }
+      }
+      double* dst = Sbase + 36ll * rd.dest + bcol;
+#pragma unroll
+      for (int m = 0; m < 3; ++m) atomic_add_f64(dst + 6 * (a0 + 2 * m), -acc[m]);
+    }
+  } else {
+    const int grp = t >> 1, h = t & 1;
+    for (int r = grp; r < n_runs; r += kBlock / 2) {
+      const RunDesc rd = runs[r];
+      const int off = rd.first_count >> 8, cnt = rd.first_count & 0xff;
+      unsigned short pr[kRunMax];
+#pragma unroll
+      for (int q = 0; q < kRunMax; ++q) pr[q] = pairs[off + q];
+      double acc[18];
+#pragma unroll
+      for (int i = 0; i < 18; ++i) acc[i] = 0.0;
+#pragma unroll
+      for (int q = 0; q < kRunMax; ++q) {
+        if (q < cnt) {
+          const int i = pr[q] & 0xff, j = pr[q] >> 8;
+          const double* Yi = sYW + kYW * i;
+          const double* Wj = sYW + kYW * j + 18 + 9 * h;
+          double wj[9];
+#pragma unroll
+          for (int ii = 0; ii < 9; ++ii) wj[ii] = Wj[ii];
+#pragma unroll
+          for (int a = 0; a < 6; ++a) {
+            const double y0 = Yi[3 * a], y1 = Yi[3 * a + 1], y2 = Yi[3 * a + 2];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[3 * a + c] += y0 * wj[3 * c] + y1 * wj[3 * c + 1] + y2 * wj[3 * c + 2];
+          }
+        }
+      }
+      double* dst = Sbase + 36ll * rd.dest + 3 * h;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) atomic_add_f64(dst + 6 * a + c, -acc[3 * a + c]);
+      }
+    }
+  }
+}
+
+// MODE 0: fp64 atomics straight into S, one workgroup per block.
+// MODE 2 (staged): every 6x6 product is written with plain stores to its precomputed slot of a staging
+//   buffer ordered by destination block; k_reduce_staged sums the slots (no atomics on S, fixed order).
+// MODE 1 / 3 (windows of at most kSmallMaxN/6 poses): `parts` workgroups per window, each walking every
+//   parts-th block of the window; b is accumulated in LDS and flushed once per workgroup, and so is the
+//   whole packed S when it fits (MODE 1; MODE 3 sends S to HBM with atomics).  A product is shared by two
+//   lanes (6x3 outputs each) instead of twelve, which halves the LDS bytes read per multiply-add.
 template <int MODE>
-__global__ __launch_bounds__(kBlock) void k_point_schur(DevP P, LmParams lm) {
-  constexpr bool LDS_ACC = MODE == 1;
+__global__ __launch_bounds__(kBlock) void k_point_schur(DevP P, LmParams lm, int parts) {
+  constexpr bool SMALL = MODE == 1 || MODE == 3;
+  constexpr bool LDS_S = MODE == 1;
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  double* sYW = smem;                         // [kBlock][36]: Y (18) then W (18); phase 1 aliases 9 words/lane
-  int* sslot = reinterpret_cast<int*>(smem + kBlock * 36);  // [kBlock] local slot or -1
-  double* red = smem + kBlock * 36 + kBlock / 2;             // [8]
-  double* accS = red + 8;                                      // LDS_ACC: packed S then b
+  double* sYW = smem;                         // [kBlock][kYW]: Y (18) then W (18); phase 1 aliases 9 words/lane
+  int* sslot = reinterpret_cast<int*>(smem + kBlock * kYW);  // [kBlock] local slot or -1
+  double* red = smem + kBlock * kYW + kBlock / 2;            // [8]
+  unsigned short* sPairs = reinterpret_cast<unsigned short*>(red + 8);   // [kLdsPairs] (not in staged mode)
+  RunDesc* sRuns = reinterpret_cast<RunDesc*>(sPairs + kLdsPairs);      // [kLdsRuns]
+  double* accB = reinterpret_cast<double*>(sRuns + kLdsRuns);           // SMALL: b, then (LDS_S) packed S
+  double* accS = accB + kSmallMaxN;
 
-  const BlockDesc d = P.blocks[blockIdx.x];
-  const int w = d.window;
+  const int t = threadIdx.x;
+  HIPBA_TICK(0);
+  int blk = blockIdx.x, blk_end = blockIdx.x + 1, blk_step = 1, w;
+  if (SMALL) {
+    w = blockIdx.x / parts;
+    const int part = blockIdx.x - w * parts;
+    blk = P.wd[w].pm_blk_begin + part;
+    blk_end = P.wd[w].pm_blk_end;
+    blk_step = parts;
+    if (blk >= blk_end) return;
+  } else {
+    w = P.blocks[blk].window;
+  }
   const WinState* st = P.ws + w;
   if (!st->active) return;
   const WinDesc wd = P.wd[w];
   const int sel = st->sel;
   const double inv_radius = 1.0 / st->radius;
-  const int t = threadIdx.x;
-  const int nS = LDS_ACC ? (wd.ncam * (wd.ncam + 1) / 2) * 36 : 0;
-  if (LDS_ACC) {
-    for (int i = t; i < nS + 6 * wd.ncam; i += kBlock) accS[i] = 0.0;
+  const int nS = LDS_S ? (wd.ncam * (wd.ncam + 1) / 2) * 36 : 0;
+  if (SMALL) {
+    for (int i = t; i < 6 * wd.ncam; i += kBlock) accB[i] = 0.0;
+    for (int i = t; i < nS; i += kBlock) accS[i] = 0.0;
   }
-
-  double r[2], Jc[12], Jp[6];
-  int pp = -1, slot = -1;
-  const bool live = t < d.n_obs;
-  if (live) {
-    const long long o = d.obs_begin + t;
-    pp = P.obs_dp[o];
-    const int c = P.obs_pose[o];
-    const int g = P.pose_gslot[c];
-    slot = g < 0 ? -1 : g - wd.cam_base;
-    const double* pose = P.poses[sel] + 7ll * c;
-    const double* p = P.points[sel] + 3ll * pp;
-    const double2 uv = reinterpret_cast<const double2*>(P.obs_uv)[o];
-    eval_obs<true>(wd.K, lm, pose, p, uv.x, uv.y, g < 0 ? nullptr : P.scale_c + 6ll * g, P.scale_p + 3ll * pp, r, Jc,
-                   Jp);
-    double* cw = sYW + 9 * t;
-    cw[0] = Jp[0] * Jp[0] + Jp[3] * Jp[3];
-    cw[1] = Jp[0] * Jp[1] + Jp[3] * Jp[4];
-    cw[2] = Jp[0] * Jp[2] + Jp[3] * Jp[5];
-    cw[3] = Jp[1] * Jp[1] + Jp[4] * Jp[4];
-    cw[4] = Jp[1] * Jp[2] + Jp[4] * Jp[5];
-    cw[5] = Jp[2] * Jp[2] + Jp[5] * Jp[5];
-    cw[6] = Jp[0] * r[0] + Jp[3] * r[1];
-    cw[7] = Jp[1] * r[0] + Jp[4] * r[1];
-    cw[8] = Jp[2] * r[0] + Jp[5] * r[1];
-  }
-  __syncthreads();
-
-  double Y[18], W[18];
   double gmax = 0.0, g2 = 0.0;
-  if (live) {
-    const int s0 = (int)(P.pp_obs_start[pp] - d.obs_begin);
-    const int s1 = (int)(P.pp_obs_start[pp + 1] - d.obs_begin);
-    double V[6] = {0, 0, 0, 0, 0, 0}, gpv[3] = {0, 0, 0};
-    for (int j = s0; j < s1; ++j) {
-      const double* cw = sYW + 9 * j;
-#pragma unroll
-      for (int i = 0; i < 6; ++i) V[i] += cw[i];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) gpv[i] += cw[6 + i];
-    }
-    // Levenberg-Marquardt diagonal: clamp(column norm^2) / radius
-    V[0] += fmin(fmax(V[0], lm.min_lm_diagonal), lm.max_lm_diagonal) * inv_radius;
-    V[3] += fmin(fmax(V[3], lm.min_lm_diagonal), lm.max_lm_diagonal) * inv_radius;
-    V[5] += fmin(fmax(V[5], lm.min_lm_diagonal), lm.max_lm_diagonal) * inv_radius;
-    double Vi[6];
-    inv3_sym(V, Vi);
-    if (t == s0) {
-#pragma unroll
-      for (int i = 0; i < 6; ++i) P.Vinv[6ll * pp + i] = Vi[i];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        P.gp[3ll * pp + i] = gpv[i];
-        const double gu = gpv[i] / P.scale_p[3ll * pp + i];
-        gmax = fmax(gmax, fabs(gu));
-        g2 += gu * gu;
-      }
-    }
-    if (slot >= 0) {
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j) W[3 * i + j] = Jc[i] * Jp[j] + Jc[6 + i] * Jp[3 + j];
-      }
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        Y[3 * i + 0] = W[3 * i] * Vi[0] + W[3 * i + 1] * Vi[1] + W[3 * i + 2] * Vi[2];
-        Y[3 * i + 1] = W[3 * i] * Vi[1] + W[3 * i + 1] * Vi[3] + W[3 * i + 2] * Vi[4];
-        Y[3 * i + 2] = W[3 * i] * Vi[2] + W[3 * i + 1] * Vi[4] + W[3 * i + 2] * Vi[5];
-      }
-      // b_c -= Y g_p
-      double* bdst = LDS_ACC ? accS + nS + 6 * slot : P.b + 6ll * (wd.cam_base + slot);
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        const double v = Y[3 * i] * gpv[0] + Y[3 * i + 1] * gpv[1] + Y[3 * i + 2] * gpv[2];
-        atomic_add_f64(bdst + i, -v);
-      }
-    }
-  }
-  __syncthreads();  // every lane has finished reading the phase-1 words
-  if (live) {
-    sslot[t] = slot;
-    if (slot >= 0) {
-      double* yw = sYW + 36 * t;
-#pragma unroll
-      for (int i = 0; i < 18; ++i) { yw[i] = Y[i]; yw[18 + i] = W[i]; }
-    }
-  }
-  __syncthreads();
+  const int first_blk = blk;
 
-  // phase 3: pair products
-  const int grp = t / kPairGroup, k = t - grp * kPairGroup;
-  if (grp < kPairGroups) {
-    const int bcol = k % 6, a0 = k / 6;
-    for (int q = grp; q < d.n_pairs; q += kPairGroups) {
-      const unsigned short pr = P.pairs[d.pair_begin + q];
-      const int i = pr & 0xff, j = pr >> 8;
-      const int si = sslot[i], sj = sslot[j];
-      const double* Yi = sYW + 36 * i;
-      const double* Wj = sYW + 36 * j + 18 + 3 * bcol;
-      const double w0 = Wj[0], w1 = Wj[1], w2 = Wj[2];
-      if (MODE == 2) {
-        double* dst = P.stage + 36ll * P.pair_slot[d.pair_begin + q];
+  for (; blk < blk_end; blk += blk_step) {
+    const BlockDesc d = P.blocks[blk];
+    if (SMALL) __syncthreads();  // accumulators zeroed / previous block's products read
+    HIPBA_TICK(1);
+    // the block's pair and run lists go to LDS when they fit; the loads are issued here, ahead of the
+    // observation work, and land in LDS together with Y and W
+    const bool lists_in_lds = MODE != 2 && d.n_pairs <= kLdsPairs && d.n_runs <= kLdsRuns;
+    uint4 pv[2] = {}, rv[2] = {};
+    if (lists_in_lds) {
+      const uint4* gp = reinterpret_cast<const uint4*>(P.pairs + d.pair_begin);
+      const uint4* gr = reinterpret_cast<const uint4*>(P.runs + d.run_begin);
+      const int npv = (d.n_pairs + 7) >> 3, nrv = (d.n_runs + 1) >> 1;
 #pragma unroll
-        for (int m = 0; m < 3; ++m) {
-          const int a = a0 + 2 * m;
-          dst[6 * a + bcol] = -(Yi[3 * a] * w0 + Yi[3 * a + 1] * w1 + Yi[3 * a + 2] * w2);
-        }
-      } else {
-        double* dst = (LDS_ACC ? accS : P.S + wd.S_off) + 36ll * tri_index(si, sj, wd.ncam);
+      for (int m = 0; m < 2; ++m) {
+        if (t + m * kBlock < npv) pv[m] = gp[t + m * kBlock];
+        if (t + m * kBlock < nrv) rv[m] = gr[t + m * kBlock];
+      }
+    }
+    double r[2], Jc[12], Jp[6];
+    int pp = -1, slot = -1;
+    const bool live = t < d.n_obs;
+    if (live) {
+      const long long o = d.obs_begin + t;
+      pp = P.obs_dp[o];
+      const int c = P.obs_pose[o];
+      const int g = P.pose_gslot[c];
+      slot = g < 0 ? -1 : g - wd.cam_base;
+      const double* pose = P.poses[sel] + 7ll * c;
+      const double* p = P.points[sel] + 3ll * pp;
+      const double2 uv = reinterpret_cast<const double2*>(P.obs_uv)[o];
+      eval_obs<true>(wd.K, lm, pose, p, uv.x, uv.y, g < 0 ? nullptr : P.scale_c + 6ll * g, P.scale_p + 3ll * pp, r,
+                     Jc, Jp);
+      double* cw = sYW + 9 * t;
+      cw[0] = Jp[0] * Jp[0] + Jp[3] * Jp[3];
+      cw[1] = Jp[0] * Jp[1] + Jp[3] * Jp[4];
+      cw[2] = Jp[0] * Jp[2] + Jp[3] * Jp[5];
+      cw[3] = Jp[1] * Jp[1] + Jp[4] * Jp[4];
+      cw[4] = Jp[1] * Jp[2] + Jp[4] * Jp[5];
+      cw[5] = Jp[2] * Jp[2] + Jp[5] * Jp[5];
+      cw[6] = Jp[0] * r[0] + Jp[3] * r[1];
+      cw[7] = Jp[1] * r[0] + Jp[4] * r[1];
+      cw[8] = Jp[2] * r[0] + Jp[5] * r[1];
+    }
+    __syncthreads();
+    HIPBA_TICK(2);
+
+    double Y[18], W[18];
+    if (live) {
+      const int s0 = (int)(P.pp_obs_start[pp] - d.obs_begin);
+      const int s1 = (int)(P.pp_obs_start[pp + 1] - d.obs_begin);
+      double V[6] = {0, 0, 0, 0, 0, 0}, gpv[3] = {0, 0, 0};
+      for (int j = s0; j < s1; ++j) {
+        const double* cw = sYW + 9 * j;
 #pragma unroll
-        for (int m = 0; m < 3; ++m) {
-          const int a = a0 + 2 * m;
-          const double v = Yi[3 * a] * w0 + Yi[3 * a + 1] * w1 + Yi[3 * a + 2] * w2;
-          atomic_add_f64(dst + 6 * a + bcol, -v);
+        for (int i = 0; i < 6; ++i) V[i] += cw[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) gpv[i] += cw[6 + i];
+      }
+      // Levenberg-Marquardt diagonal: clamp(column norm^2) / radius
+      V[0] += fmin(fmax(V[0], lm.min_lm_diagonal), lm.max_lm_diagonal) * inv_radius;
+      V[3] += fmin(fmax(V[3], lm.min_lm_diagonal), lm.max_lm_diagonal) * inv_radius;
+      V[5] += fmin(fmax(V[5], lm.min_lm_diagonal), lm.max_lm_diagonal) * inv_radius;
+      double Vi[6];
+      inv3_sym(V, Vi);
+      if (t == s0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) P.Vinv[6ll * pp + i] = Vi[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          P.gp[3ll * pp + i] = gpv[i];
+          const double gu = gpv[i] / P.scale_p[3ll * pp + i];
+          gmax = fmax(gmax, fabs(gu));
+          g2 += gu * gu;
         }
       }
+      if (slot >= 0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+#pragma unroll
+          for (int j = 0; j < 3; ++j) W[3 * i + j] = Jc[i] * Jp[j] + Jc[6 + i] * Jp[3 + j];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          Y[3 * i + 0] = W[3 * i] * Vi[0] + W[3 * i + 1] * Vi[1] + W[3 * i + 2] * Vi[2];
+          Y[3 * i + 1] = W[3 * i] * Vi[1] + W[3 * i + 1] * Vi[3] + W[3 * i + 2] * Vi[4];
+          Y[3 * i + 2] = W[3 * i] * Vi[2] + W[3 * i + 1] * Vi[4] + W[3 * i + 2] * Vi[5];
+        }
+        // b_c -= Y g_p
+        double* bdst = SMALL ? accB + 6 * slot : P.b + 6ll * (wd.cam_base + slot);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          const double v = Y[3 * i] * gpv[0] + Y[3 * i + 1] * gpv[1] + Y[3 * i + 2] * gpv[2];
+          atomic_add_f64(bdst + i, -v);
+        }
+      }
+    }
+    __syncthreads();  // every lane has finished reading the phase-1 words
+    HIPBA_TICK(3);
+    if (lists_in_lds) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        reinterpret_cast<uint4*>(sPairs)[t + m * kBlock] = pv[m];
+        reinterpret_cast<uint4*>(sRuns)[t + m * kBlock] = rv[m];
+      }
+    }
+    if (live) {
+      sslot[t] = slot;
+      if (slot >= 0) {
+        double* yw = sYW + kYW * t;
+#pragma unroll
+        for (int i = 0; i < 18; ++i) { yw[i] = Y[i]; yw[18 + i] = W[i]; }
+      }
+    }
+    __syncthreads();
+    HIPBA_TICK(4);
+
+    // phase 3: pair products (staged mode: every product to its own slot; otherwise run by run)
+    if (MODE == 2) {
+      const int grp = t / kPairGroup, k = t - grp * kPairGroup;
+      if (grp < kPairGroups) {
+        const int bcol = k % 6, a0 = k / 6;
+        for (int q = grp; q < d.n_pairs; q += kPairGroups) {
+          const unsigned short pr = P.pairs[d.pair_begin + q];
+          const int i = pr & 0xff, j = pr >> 8;
+          const double* Yi = sYW + kYW * i;
+          const double* Wj = sYW + kYW * j + 18 + 3 * bcol;
+          const double w0 = Wj[0], w1 = Wj[1], w2 = Wj[2];
+          double* dst = P.stage + 36ll * P.pair_slot[d.pair_begin + q];
+#pragma unroll
+          for (int m = 0; m < 3; ++m) {
+            const int a = a0 + 2 * m;
+            dst[6 * a + bcol] = -(Yi[3 * a] * w0 + Yi[3 * a + 1] * w1 + Yi[3 * a + 2] * w2);
+          }
+        }
+      }
+    } else {
+      double* Sbase = LDS_S ? accS : P.S + wd.S_off;
+      if (lists_in_lds) pair_products<!LDS_S>(sPairs, sRuns, d.n_runs, sYW, Sbase, t);
+      else pair_products<!LDS_S>(P.pairs + d.pair_begin, P.runs + d.run_begin, d.n_runs, sYW, Sbase, t);
     }
   }
 
-  // landmark part of the gradient norms
+  HIPBA_TICK(5);
+  // landmark part of the gradient norms: one entry per block; a workgroup that walked several blocks
+  // reports under its first one and zeroes the others
   gmax = block_max(gmax, red);
   double gs[1] = {g2};
   block_sum<1>(gs, red);
   if (t == 0) {
-    P.gpart[2ll * blockIdx.x + 0] = gmax;
-    P.gpart[2ll * blockIdx.x + 1] = gs[0];
+    P.gpart[2ll * first_blk + 0] = gmax;
+    P.gpart[2ll * first_blk + 1] = gs[0];
+    if (SMALL) {
+      for (int bb = first_blk + blk_step; bb < blk_end; bb += blk_step) {
+        P.gpart[2ll * bb + 0] = 0.0;
+        P.gpart[2ll * bb + 1] = 0.0;
+      }
+    }
   }
-  if (LDS_ACC) {
+  HIPBA_TICK(6);
+  if (SMALL) {
     __syncthreads();
     double* Sg = P.S + wd.S_off;
     for (int i = t; i < nS; i += kBlock) {
@@ -479,10 +618,11 @@ __global__ __launch_bounds__(kBlock) void k_point_schur(DevP P, LmParams lm) {
     }
     double* bg = P.b + 6ll * wd.cam_base;
     for (int i = t; i < 6 * wd.ncam; i += kBlock) {
-      const double v = accS[nS + i];
+      const double v = accB[i];
       if (v != 0.0) atomic_add_f64(bg + i, v);
     }
   }
+  HIPBA_TICK(7);
 }
 
 // staged mode: S(block d) += sum of its staged 6x6 contributions; 36 lanes per destination block,
@@ -713,7 +853,7 @@ __device__ void window_gradient_check(const DevP& P, const LmParams& lm, const W
   double gm = 0.0;
   double g2[1] = {0.0};
   if (mode != kDecide) {
-    for (int b = wd.pm_blk_begin + threadIdx.x; b < wd.pm_blk_end; b += kBlock) {
+    for (int b = wd.pm_blk_begin + threadIdx.x; b < wd.pm_blk_end; b += blockDim.x) {
       gm = fmax(gm, P.gpart[2ll * b]);
       g2[0] += P.gpart[2ll * b + 1];
     }
@@ -726,7 +866,7 @@ __device__ void window_gradient_check(const DevP& P, const LmParams& lm, const W
   }
   double pm = 0.0;
   double p2[1] = {0.0};
-  for (int g = wd.cam_base + threadIdx.x; g < wd.cam_base + wd.ncam; g += kBlock) {
+  for (int g = wd.cam_base + threadIdx.x; g < wd.cam_base + wd.ncam; g += blockDim.x) {
     pm = fmax(pm, P.yc[6ll * g]);
     p2[0] += P.yc[6ll * g + 1];
   }
@@ -864,9 +1004,70 @@ __global__ __launch_bounds__(kBlock) void k_window_control(DevP P, LmParams lm, 
 // reduced solve for small windows: gradient check, then Cholesky of the packed S in LDS
 // (one workgroup per window, n = 6 * ncam <= kSmallMaxN)
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ int lidx(int i, int k) { return i * (i + 1) / 2 + k; }  // packed lower, k <= i
 
-__global__ __launch_bounds__(kBlock) void k_window_solve_small(DevP P, LmParams lm) {
+constexpr int kSolveThreads = 512;
+
+// index of entry (a, c), a <= c, in a row-major packed upper triangle of order 6
+#define HIPBA_UIDX(a, c) ((a) * 6 - (a) * ((a) - 1) / 2 + ((c) - (a)))
+
+// Cholesky factor R (upper, R^T R = D) of the 6x6 block at D, replaced in place by R^-1 (upper
+// triangle only; the words below the diagonal are left alone).  One lane.  Returns false on a
+// non-positive or non-finite pivot.
+__device__ __forceinline__ bool factor_invert_6x6(double* D) {
+  double U[21], dinv[6];
+  {
+    int q = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+#pragma unroll
+      for (int c = a; c < 6; ++c) U[q++] = D[6 * a + c];
+    }
+  }
+  bool ok = true;
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    double dg = U[HIPBA_UIDX(a, a)];
+#pragma unroll
+    for (int mm = 0; mm < a; ++mm) dg -= U[HIPBA_UIDX(mm, a)] * U[HIPBA_UIDX(mm, a)];
+    if (!(dg > 0.0) || !isfinite(dg)) ok = false;
+    // 1/sqrt: hardware estimate + two Newton steps (full double precision, no division)
+    double inv = __builtin_amdgcn_rsq(dg);
+    inv = inv * (1.5 - 0.5 * dg * inv * inv);
+    inv = inv * (1.5 - 0.5 * dg * inv * inv);
+    dinv[a] = inv;
+#pragma unroll
+    for (int c = a + 1; c < 6; ++c) {
+      double v = U[HIPBA_UIDX(a, c)];
+#pragma unroll
+      for (int mm = 0; mm < a; ++mm) v -= U[HIPBA_UIDX(mm, a)] * U[HIPBA_UIDX(mm, c)];
+      U[HIPBA_UIDX(a, c)] = v * inv;
+    }
+  }
+  // X = R^-1: X(a,a) = 1/R(a,a), X(a,c) = -(sum_{a<=m<c} X(a,m) R(m,c)) / R(c,c)
+  double X[21];
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    X[HIPBA_UIDX(a, a)] = dinv[a];
+#pragma unroll
+    for (int c = a + 1; c < 6; ++c) {
+      double v = 0.0;
+#pragma unroll
+      for (int mm = a; mm < c; ++mm) v += X[HIPBA_UIDX(a, mm)] * U[HIPBA_UIDX(mm, c)];
+      X[HIPBA_UIDX(a, c)] = -v * dinv[c];
+    }
+  }
+  {
+    int q = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+#pragma unroll
+      for (int c = a; c < 6; ++c) D[6 * a + c] = X[q++];
+    }
+  }
+  return ok;
+}
+
+__global__ __launch_bounds__(kSolveThreads) void k_window_solve_small(DevP P, LmParams lm) {
   // all LDS comes from the dynamic region so that its base stays 16-byte aligned
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* red = smem;                                  // [8]
@@ -874,80 +1075,188 @@ __global__ __launch_bounds__(kBlock) void k_window_solve_small(DevP P, LmParams 
   const int w = blockIdx.x;
   WinState* st = P.ws + w;
   if (!st->active) return;
+  HIPBA_TICK(0);
   const WinDesc wd = P.wd[w];
   window_gradient_check(P, lm, wd, st, red, kFused);
+  HIPBA_TICK(1);
   if (!st->active) return;
-  const int n = 6 * wd.ncam;
-  if (n == 0) return;
-  // augmented packed lower matrix: rows 0..n-1 = S, row n = b^T (its Cholesky row is L^-1 b)
-  double* A = smem + 10;
+  const int nb = wd.ncam;
+  if (nb == 0) return;
+  // S = R^T R by 6x6 blocks, in the packed upper block order S already has in HBM (the load is a
+  // straight copy).  Blocks are padded to kSmallBlk doubles: an odd stride, so lanes that work on
+  // neighbouring blocks hit different LDS banks.  A factored diagonal block is kept as its inverse.
+  double* Rm = smem + 16;
   const int t = threadIdx.x;
-  const int nblk = wd.ncam * (wd.ncam + 1) / 2;
+  const int nblk = nb * (nb + 1) / 2;
+  double* zb = Rm + (size_t)nblk * kSmallBlk;          // right-hand side, becomes z = R^-T b
   const double* Sg = P.S + wd.S_off;
-  // block (bi,bj), bi<=bj, entry (a,c) = S[6bi+a][6bj+c] -> lower element (6bj+c, 6bi+a)
-  for (int e = t; e < nblk * 36; e += kBlock) {
-    const int blk = e / 36, ac = e - blk * 36;
-    const int a = ac / 6, c = ac - a * 6;
-    // decode blk -> (bi,bj)
-    int bi = 0, rem = blk;
-    while (rem >= wd.ncam - bi) { rem -= wd.ncam - bi; ++bi; }
-    const int bj = bi + rem;
-    const int row = 6 * bj + c, col = 6 * bi + a;
-    if (row >= col) A[lidx(row, col)] = Sg[e];
+  for (int e0 = t; e0 < nblk * 36; e0 += 8 * kSolveThreads) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + u * kSolveThreads;
+      v[u] = e < nblk * 36 ? Sg[e] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + u * kSolveThreads;
+      if (e < nblk * 36) {
+        const int blk = e / 36;
+        Rm[blk * kSmallBlk + (e - blk * 36)] = v[u];
+      }
+    }
   }
-  for (int i = t; i < n; i += kBlock) A[lidx(n, i)] = P.b[6ll * wd.cam_base + i];
+  for (int i = t; i < 6 * nb; i += kSolveThreads) zb[i] = P.b[6ll * wd.cam_base + i];
   if (t == 0) fail = 0;
   __syncthreads();
-  const int ti = t & 15, tk = t >> 4;
-  for (int j = 0; j < n; ++j) {
-    const double djj = A[lidx(j, j)];
-    if (!(djj > 0.0) || !isfinite(djj)) {
-      if (t == 0) fail = 1;
-      break;  // uniform: every thread reads the same word
+  if (t == 0 && !factor_invert_6x6(Rm)) fail = 1;
+  __syncthreads();
+  HIPBA_TICK(2);
+  HIPBA_CYCLES(5);
+
+  for (int k = 0; k < nb; ++k) {
+    const int m = nb - k - 1;                           // block columns to the right of the diagonal
+    const int rowk = (int)tri_index(k, k, nb);          // blocks (k, k..nb-1) are contiguous from here
+    // block row k: R(k,j) = R(k,k)^-T S(k,j), one lane per column; one more lane for the right-hand side
+    if (t < 6 * m + 1) {
+      const double* X = Rm + rowk * kSmallBlk;          // R(k,k)^-1, upper
+      const bool rhs = t == 6 * m;
+      const int jj = t / 6, c = t - 6 * jj;
+      double* col = rhs ? zb + 6 * k : Rm + (rowk + 1 + jj) * kSmallBlk + c;
+      const int stride = rhs ? 1 : 6;
+      double x[6], y[6];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) x[a] = col[stride * a];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        double v = 0.0;
+#pragma unroll
+        for (int mm = 0; mm <= a; ++mm) v += X[6 * mm + a] * x[mm];
+        y[a] = v;
+      }
+#pragma unroll
+      for (int a = 0; a < 6; ++a) col[stride * a] = y[a];
     }
-    const double inv = 1.0 / sqrt(djj);
     __syncthreads();
-    for (int i = j + t; i <= n; i += kBlock) A[lidx(i, j)] *= inv;  // includes (j,j) -> sqrt, and row n
-    __syncthreads();
-    // trailing update of rows j+1..n (row n carries the right-hand side)
-    for (int i = j + 1 + ti; i <= n; i += 16) {
-      const double lij = A[lidx(i, j)];
-      const int kend = i < n ? i : n - 1;
-      for (int k = j + 1 + tk; k <= kend; k += 16) A[lidx(i, k)] -= lij * A[lidx(k, j)];
+    // trailing update S(i,j) -= R(k,i)^T R(k,j), k < i <= j.  Lane 0 takes the next diagonal block whole and
+    // factors it on the spot (that chain runs beside the other lanes' updates); the other lanes take half
+    // blocks (3 rows x 6 columns), pairs enumerated row by row so that a wave's lanes share R(k,i) and walk
+    // consecutive blocks; the last m items update the right-hand side.
+    const int npair = m * (m + 1) / 2;
+    const int nitem = 2 * npair + m;
+    if (t == 0) {
+      if (m > 0) {
+        const double* Ri = Rm + (rowk + 1) * kSmallBlk;
+        double* T = Rm + (int)tri_index(k + 1, k + 1, nb) * kSmallBlk;
+        double ri[36];
+#pragma unroll
+        for (int i = 0; i < 36; ++i) ri[i] = Ri[i];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+#pragma unroll
+          for (int c = a; c < 6; ++c) {
+            double v = T[6 * a + c];
+#pragma unroll
+            for (int mm = 0; mm < 6; ++mm) v -= ri[6 * mm + a] * ri[6 * mm + c];
+            T[6 * a + c] = v;
+          }
+        }
+        if (!factor_invert_6x6(T)) fail = 1;
+      }
+    } else {
+      for (int e = 1 + t; e < nitem; e += kSolveThreads - 1) {
+        if (e < 2 * npair) {
+          const int p = e >> 1, h = e & 1;
+          // row ii of an m-row upper triangle starts at ii*m - ii(ii-1)/2
+          const float fm = 2.0f * m + 1.0f;
+          int ii = (int)((fm - sqrtf(fm * fm - 8.0f * p)) * 0.5f);
+          ii = max(0, min(ii, m - 1));
+          while (ii > 0 && ii * m - ii * (ii - 1) / 2 > p) --ii;
+          while ((ii + 1) * m - (ii + 1) * ii / 2 <= p) ++ii;
+          const int jj = ii + (p - (ii * m - ii * (ii - 1) / 2));
+          const double* Ri = Rm + (rowk + 1 + ii) * kSmallBlk + 3 * h;
+          const double* Rj = Rm + (rowk + 1 + jj) * kSmallBlk;
+          double* T = Rm + (int)tri_index(k + 1 + ii, k + 1 + jj, nb) * kSmallBlk + 18 * h;
+          double acc[18];
+#pragma unroll
+          for (int i = 0; i < 18; ++i) acc[i] = T[i];
+#pragma unroll
+          for (int mm = 0; mm < 6; ++mm) {
+            double rj[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) rj[c] = Rj[6 * mm + c];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+              const double ri = Ri[6 * mm + a];
+#pragma unroll
+              for (int c = 0; c < 6; ++c) acc[6 * a + c] -= ri * rj[c];
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < 18; ++i) T[i] = acc[i];
+        } else {
+          const int ii = e - 2 * npair;
+          const double* Ri = Rm + (rowk + 1 + ii) * kSmallBlk;
+          double* z = zb + 6 * (k + 1 + ii);
+          double acc[6];
+#pragma unroll
+          for (int a = 0; a < 6; ++a) acc[a] = z[a];
+#pragma unroll
+          for (int mm = 0; mm < 6; ++mm) {
+            const double zk = zb[6 * k + mm];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) acc[a] -= Ri[6 * mm + a] * zk;
+          }
+#pragma unroll
+          for (int a = 0; a < 6; ++a) z[a] = acc[a];
+        }
+      }
     }
     __syncthreads();
   }
-  __syncthreads();
+  HIPBA_TICK(3);
+  HIPBA_CYCLES(6);
   if (fail) {
     if (t == 0) st->solve_failed = 1;
     return;
   }
-  // backward substitution L^T y = z by one wave: lane l owns rows l, l+64, l+128
+  // backward sweep R y = z, last block row first: every lane forms y(k) = R(k,k)^-1 z(k) itself, then one
+  // lane per row above subtracts that block column's contribution
+  bool ok = true;
+  for (int k = nb - 1; k >= 0; --k) {
+    const double* X = Rm + (int)tri_index(k, k, nb) * kSmallBlk;
+    double zk[6], y[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) zk[a] = zb[6 * k + a];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      double v = 0.0;
+#pragma unroll
+      for (int c = a; c < 6; ++c) v += X[6 * a + c] * zk[c];
+      y[a] = v;
+    }
+    if (t < 6) {
+      const double v = t == 0 ? y[0] : t == 1 ? y[1] : t == 2 ? y[2] : t == 3 ? y[3] : t == 4 ? y[4] : y[5];
+      P.yc[6ll * (wd.cam_base + k) + t] = v;
+      ok = ok && isfinite(v);
+    }
+    for (int e = t; e < 6 * k; e += kSolveThreads) {
+      const int i = e / 6, a = e - 6 * i;
+      const double* B = Rm + (int)tri_index(i, k, nb) * kSmallBlk + 6 * a;
+      double v = zb[e];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) v -= B[c] * y[c];
+      zb[e] = v;
+    }
+    __syncthreads();
+  }
+  HIPBA_TICK(4);
   if (t < 64) {
-    double z[3];
-#pragma unroll
-    for (int m = 0; m < 3; ++m) { const int i = t + 64 * m; z[m] = i < n ? A[lidx(n, i)] : 0.0; }
-    for (int j = n - 1; j >= 0; --j) {
-      const int owner = j & 63, m = j >> 6;
-      double zj = (m == 0 ? z[0] : (m == 1 ? z[1] : z[2])) / A[lidx(j, j)];
-      zj = __shfl(zj, owner);
-      if (t == owner) { if (m == 0) z[0] = zj; else if (m == 1) z[1] = zj; else z[2] = zj; }
-#pragma unroll
-      for (int mm = 0; mm < 3; ++mm) {
-        const int i = t + 64 * mm;
-        if (i < j) z[mm] -= A[lidx(j, i)] * zj;
-      }
-    }
-    bool ok = true;
-#pragma unroll
-    for (int m = 0; m < 3; ++m) {
-      const int i = t + 64 * m;
-      if (i < n) { P.yc[6ll * wd.cam_base + i] = z[m]; ok = ok && isfinite(z[m]); }
-    }
     const unsigned long long okm = __ballot(ok);
     if (t == 0 && okm != ~0ull) st->solve_failed = 1;
   }
 }
+#undef HIPBA_UIDX
 
 // gradient check alone, for windows whose reduced system is solved by the large-matrix path
 __global__ __launch_bounds__(kBlock) void k_window_gradient(DevP P, LmParams lm, int mode) {
@@ -1018,9 +1327,15 @@ __global__ void k_count_active(DevP P, int* out) {
 // ------------------------------------------------------------------------------------------
 // launch wrappers (called from the host driver)
 // ------------------------------------------------------------------------------------------
-size_t schur_lds_bytes(int max_ncam_lds) {
-  size_t base = (size_t)kBlock * 36 * 8 + (size_t)kBlock * 4 + 8 * 8;
-  if (max_ncam_lds > 0) base += ((size_t)max_ncam_lds * (max_ncam_lds + 1) / 2 * 36 + 6 * (size_t)max_ncam_lds) * 8;
+// LDS of k_point_schur: Y/W staging, slots, reduction words; outside staged mode the block's pair and run
+// lists; the small-window modes add b and, up to kLdsSMaxCam poses, the packed S
+size_t schur_lds_bytes(int small_ncam, bool staged) {
+  size_t base = (size_t)kBlock * kYW * 8 + (size_t)kBlock * 4 + 8 * 8;
+  if (!staged) base += (size_t)kLdsPairs * 2 + (size_t)kLdsRuns * sizeof(RunDesc);
+  if (small_ncam > 0) {
+    base += (size_t)kSmallMaxN * 8;
+    if (small_ncam <= kLdsSMaxCam) base += (size_t)small_ncam * (small_ncam + 1) / 2 * 36 * 8;
+  }
   return base;
 }
 
@@ -1057,7 +1372,7 @@ hipError_t launch_init_reduced(const DevP& P, const LmParams& lm, int owner, hip
   return hipGetLastError();
 }
 
-hipError_t launch_point_schur(const DevP& P, const LmParams& lm, int lds_acc_ncam, hipStream_t s) {
+hipError_t launch_point_schur(const DevP& P, const LmParams& lm, int small_ncam, int parts, hipStream_t s) {
   if (P.n_blk_pm <= 0) return hipSuccess;
   static bool attr_done = false;
   if (!attr_done) {
@@ -1067,19 +1382,26 @@ hipError_t launch_point_schur(const DevP& P, const LmParams& lm, int lds_acc_nca
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_point_schur<2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_point_schur<3>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  const size_t lds = schur_lds_bytes(lds_acc_ncam);
   if (P.stage) {
-    hipLaunchKernelGGL(k_point_schur<2>, dim3(P.n_blk_pm), dim3(kBlock), lds, s, P, lm);
+    hipLaunchKernelGGL(k_point_schur<2>, dim3(P.n_blk_pm), dim3(kBlock), schur_lds_bytes(0, true), s, P, lm, 1);
     const long long n_dest = P.n_dest;
     const long long want = (n_dest + 6) / 7;
     const unsigned grid = (unsigned)(want < 16384 ? want : 16384);
     hipLaunchKernelGGL(k_reduce_staged, dim3(grid), dim3(kBlock), 0, s, P, n_dest);
-  } else if (lds_acc_ncam > 0) {
-    hipLaunchKernelGGL(k_point_schur<1>, dim3(P.n_blk_pm), dim3(kBlock), lds, s, P, lm);
+  } else if (small_ncam > 0) {
+    if (parts < 1) parts = 1;
+    const size_t lds = schur_lds_bytes(small_ncam, false);
+    const unsigned grid = (unsigned)P.n_windows * (unsigned)parts;
+    if (small_ncam <= kLdsSMaxCam)
+      hipLaunchKernelGGL(k_point_schur<1>, dim3(grid), dim3(kBlock), lds, s, P, lm, parts);
+    else
+      hipLaunchKernelGGL(k_point_schur<3>, dim3(grid), dim3(kBlock), lds, s, P, lm, parts);
   } else {
-    hipLaunchKernelGGL(k_point_schur<0>, dim3(P.n_blk_pm), dim3(kBlock), lds, s, P, lm);
+    hipLaunchKernelGGL(k_point_schur<0>, dim3(P.n_blk_pm), dim3(kBlock), schur_lds_bytes(0, false), s, P, lm, 1);
   }
   return hipGetLastError();
 }
@@ -1091,8 +1413,9 @@ hipError_t launch_window_solve_small(const DevP& P, const LmParams& lm, int max_
                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
     attr_done = true;
   }
-  const size_t lds = ((size_t)(max_n + 1) * (max_n + 2) / 2 + 10) * 8 + 16;
-  hipLaunchKernelGGL(k_window_solve_small, dim3(P.n_windows), dim3(kBlock), lds, s, P, lm);
+  const size_t nb = (size_t)(max_n + 5) / 6;
+  const size_t lds = (16 + nb * (nb + 1) / 2 * kSmallBlk + 6 * nb) * 8;
+  hipLaunchKernelGGL(k_window_solve_small, dim3(P.n_windows), dim3(kSolveThreads), lds, s, P, lm);
   return hipGetLastError();
 }
 
@@ -1141,3 +1464,9 @@ hipError_t launch_residual_jacobian(const CameraK& K, const LmParams& lm, int ap
 }
 
 }  // namespace hipba
+
+#ifdef HIPBA_PHASE_TIMING
+extern "C" int hipba_debug_ticks(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hipba::g_ticks), sizeof(unsigned long long) * n);
+}
+#endif
