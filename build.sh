@@ -20,3 +20,7 @@ echo "built $OUT/libhipba.so"
 # C++ host adapter demo: the ROS-free ba_test harness (plain g++, links the C ABI only)
 g++ -O2 -std=c++17 -Wall -Iinclude -I$SRC/host -o $OUT/ba_test $SRC/host/ba_test_cli.cpp -L$OUT -lhipba -Wl,-rpath,'$ORIGIN'
 echo "built $OUT/ba_test"
+g++ -O2 -std=c++17 -Wall -Iinclude -I$SRC/host -o $OUT/ba_replay $SRC/host/ba_replay_cli.cpp -L$OUT -lhipba -Wl,-rpath,'$ORIGIN'
+echo "built $OUT/ba_replay"
+g++ -O2 -std=c++17 -Wall -pthread -Iinclude -I$SRC/host -o $OUT/ba_stage_demo $SRC/host/ba_stage_demo.cpp -L$OUT -lhipba -Wl,-rpath,'$ORIGIN'
+echo "built $OUT/ba_stage_demo"

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "hipba.h"
+#include "window_io.hpp"
 
 namespace VO {
 
@@ -114,11 +115,28 @@ public:
     hipba_options options;
     hipba_options_default(&options);
     options.max_num_iterations = 300;          // optimizer.cpp:58
-    options.minimizer_progress_to_stdout = 1;  // optimizer.cpp:56 (and the FullReport of line 62)
-    last_summary_ = optimizeMap(handle_, map, K, HIPBA_CAMERA_Z_FORWARD, /*first_frame_constant=*/true, options);
+    options.minimizer_progress_to_stdout = progress_to_stdout_ ? 1 : 0;  // optimizer.cpp:56 (+ the report of line 62)
+    FlatWindow w;
+    flattenMap(map, K, HIPBA_CAMERA_Z_FORWARD, /*first_frame_constant=*/true, &w);
+    if (!dump_directory_.empty()) {
+      // capture hook: the window exactly as the solver receives it, for replay on a machine without the frontend
+      char name[64];
+      snprintf(name, sizeof name, "/window_%06d.%s", num_calls_, dump_binary_ ? "bin" : "txt");
+      writeWindow(dump_directory_ + name, w.problem, dump_binary_);
+    }
+    ++num_calls_;
+    hipba_summary summary{};
+    if (hipba_solve(handle_, &w.problem, &options, &summary) != HIPBA_OK)
+      throw std::runtime_error(std::string("hipba_solve: ") + hipba_last_error());
+    if (summary.termination_type != HIPBA_FAILURE) writeBack(w);
+    last_summary_ = summary;
   }
 
   int device_ = 0;
+  bool progress_to_stdout_ = true;
+  std::string dump_directory_;   // when set, every window is written there before it is solved
+  bool dump_binary_ = false;
+  int num_calls_ = 0;
   hipba_summary last_summary_{};
 
 private:

@@ -2,7 +2,8 @@
 // dependency-free stand-ins for the Sophus / Eigen / OpenCV value types (none of which are installed
 // here).  Member names and memory layouts are the reference's, so code written against these types
 // compiles unchanged against the real headers:
-//   VO::Map       landmarks_, frames_, insertFrame, insertLandmark   (sensor/map.hpp:13-25, map.cpp:8-21)
+//   VO::Map       landmarks_, frames_, insertFrame, insertLandmark,
+//                 cleanMap                                           (sensor/map.hpp:13-25, map.cpp:8-50)
 //   VO::Frame     pose_, features_left_, pushFeatureLeftWithLandmark (sensor/frame.hpp:15-39, frame.cpp:20-25)
 //   VO::Feature   frame_, pixel, landmark_                           (sensor/feature.hpp:15-33)
 //   VO::MapPoint  pose_, observations_                               (sensor/map_point.hpp:12-22)
@@ -85,6 +86,17 @@ public:
     if (frames_.size() > num_active_frames_) frames_.pop_front();
   }
   void insertLandmark(const std::shared_ptr<MapPoint>& landmark) { landmarks_.insert(landmark); }
+  // erases the landmarks whose observing features have all expired (map.cpp:23-50); returns how many
+  int cleanMap() {
+    int removed = 0;
+    for (auto it = landmarks_.begin(); it != landmarks_.end();) {
+      bool all_expired = true;
+      for (const std::weak_ptr<Feature>& feature : (*it)->observations_) all_expired = all_expired && feature.expired();
+      if (all_expired) { it = landmarks_.erase(it); ++removed; }
+      else ++it;
+    }
+    return removed;
+  }
   std::unordered_set<std::shared_ptr<MapPoint>> landmarks_;
   std::deque<std::shared_ptr<Frame>> frames_;
   const unsigned int num_active_frames_{30};

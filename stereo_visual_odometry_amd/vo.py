@@ -6,6 +6,8 @@ reference's ``test/ba_test.cpp``:
   Map / Frame / Feature / MapPoint   reference: include/visual_odometry/sensor/{map,frame,feature,map_point}.hpp
   Optimizer.optimize(map, K)         reference: include/visual_odometry/solve/optimizer.hpp:18,
                                                 src/solve/optimizer.cpp:14-63
+  BundleAdjustmentStage.step(...)    reference: src/frontend.cpp:65-84 (window insert, landmark GC, BA trigger,
+                                                trajectory splice)
 
 ``Optimizer.optimize`` flattens the map exactly as the reference builds its ceres::Problem
 (frames oldest first, first frame and the landmarks it observes held constant, one residual
@@ -65,6 +67,16 @@ class Map:
     def insertLandmark(self, landmark):
         self.landmarks_.append(landmark)
 
+    def cleanMap(self, keep_frames=()):
+        """reference: src/sensor/map.cpp:23-50 -- erase the landmarks whose observing features have all expired.
+        A feature lives as long as its frame does: in the window, or held by the caller (the reference's
+        context_.frame_prev_/frame_curr_, passed here as keep_frames).  Returns the number removed."""
+        alive = {id(f) for f in self.frames_} | {id(f) for f in keep_frames}
+        kept = [lm for lm in self.landmarks_ if any(id(ft.frame_) in alive for ft in lm.observations_)]
+        removed = len(self.landmarks_) - len(kept)
+        self.landmarks_ = kept
+        return removed
+
 
 def flatten_map(map_, K, camera_model=hipba.CAMERA_Z_FORWARD, first_frame_constant=True):
     """Map -> hipba.Problem in canonical order (frames oldest first, landmarks by first appearance while
@@ -112,17 +124,56 @@ def write_back(map_, lms, prob):
 class Optimizer:
     """reference: VO::Optimizer (optimizer.hpp:14-19).  Stateless apart from the GPU handle."""
 
-    def __init__(self, device=0, progress_to_stdout=False):
+    def __init__(self, device=0, progress_to_stdout=False, dump_directory=None, dump_binary=False):
         self.solver = hipba.Solver(device)
         self.progress_to_stdout = progress_to_stdout
         self.last_summary = None
+        self.dump_directory = dump_directory  # capture hook: every window is written there before it is solved
+        self.dump_binary = dump_binary
+        self.num_calls = 0
 
     def optimize(self, map_, K):
         """Drop-in for ``optimizer_.optimize(map_, camera_left_.K_)`` (reference: src/frontend.cpp:73):
         z-forward camera, first frame and its landmarks constant, no loss, 300 iterations
         (optimizer.cpp:28-36, 48, 58).  Updates the map in place; returns nothing, like the reference."""
         prob, lms = flatten_map(map_, K, hipba.CAMERA_Z_FORWARD, first_frame_constant=True)
+        if self.dump_directory:
+            from .windows import save_window
+            save_window("%s/window_%06d.%s" % (self.dump_directory, self.num_calls, "bin" if self.dump_binary else "txt"),
+                        prob, self.dump_binary)
+        self.num_calls += 1
         opts = hipba.reference_production_options(
             minimizer_progress_to_stdout=1 if self.progress_to_stdout else 0)
         self.last_summary = self.solver.solve(prob, opts)
         write_back(map_, lms, prob)
+
+
+class BundleAdjustmentStage:
+    """The tail of ``Frontend::visualOdometryPipeline`` (reference: src/frontend.cpp:65-84): window insert, landmark
+    GC, the BA trigger and the trajectory splice, quirks included (the non-BA branch appends the PREVIOUS
+    frame's pose, frontend.cpp:81; a trajectory shorter than the window is cleared, frontend.cpp:75).
+    `optimizer` is anything with ``optimize(map, K)``."""
+
+    def __init__(self, optimizer, do_bundle_adjustment=False, bundle_adjustment_window=20):
+        self.optimizer_ = optimizer
+        self.do_bundle_adjustment_ = do_bundle_adjustment          # frontend.hpp:32
+        self.bundle_adjustment_window_ = bundle_adjustment_window  # frontend.hpp:35
+        self.poses_ = []                                           # frontend.hpp:29
+        self.iterations_ = 1                                       # frontend.hpp:51
+        self.num_optimizations_ = 0
+
+    def step(self, map_, frame_prev, frame_curr, K):
+        map_.insertFrame(frame_curr)                       # frontend.cpp:66
+        map_.cleanMap(keep_frames=(frame_prev, frame_curr))  # frontend.cpp:68
+        if self.do_bundle_adjustment_ and self.iterations_ % self.bundle_adjustment_window_ == 0:
+            self.optimizer_.optimize(map_, K)              # frontend.cpp:73
+            n = len(map_.frames_)
+            if len(self.poses_) < n:                       # frontend.cpp:75-77
+                self.poses_.clear()
+            else:
+                del self.poses_[len(self.poses_) - n:]
+            self.poses_.extend(f.pose_.copy() for f in map_.frames_)
+            self.num_optimizations_ += 1
+        else:
+            self.poses_.append(frame_prev.pose_.copy())    # frontend.cpp:81
+        self.iterations_ += 1

@@ -1,0 +1,230 @@
+"""Window files (hipba-window 1) and the caller-side stage: CPU tests of the formats and the host logic;
+GPU tests that captured windows replay to the same result through the C++ tools."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from stereo_visual_odometry_amd import hipba, scenes, vo, windows
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(os.path.dirname(HERE), "stereo_visual_odometry_amd", "lib")
+
+
+def _same(a, b):
+    assert a.camera_model == b.camera_model and a.K == b.K
+    for name in ("poses", "points", "obs_pose", "obs_point", "obs_uv", "pose_const", "point_const"):
+        x, y = getattr(a, name), getattr(b, name)
+        assert np.array_equal(np.asarray(x), np.asarray(y)), name
+
+
+@pytest.mark.parametrize("binary", [False, True])
+def test_window_round_trip_is_exact(tmp_path, binary):
+    prob = scenes.small_window(5, n_frames=6, n_points=300)[0]
+    path = str(tmp_path / "w")
+    windows.save_window(path, prob, binary)
+    _same(prob, windows.load_window(path))
+
+
+def test_window_round_trip_x_forward_and_no_flags(tmp_path):
+    prob = scenes.small_window(6, n_frames=4, n_points=50)[0]
+    prob = hipba.Problem(prob.poses, prob.points, prob.obs_pose, prob.obs_point, prob.obs_uv, prob.K,
+                         hipba.CAMERA_X_FORWARD, None, None)
+    path = str(tmp_path / "w.txt")
+    windows.save_window(path, prob)
+    back = windows.load_window(path)
+    assert back.camera_model == hipba.CAMERA_X_FORWARD
+    assert not back.pose_const.any() and not back.point_const.any()
+    assert np.array_equal(back.poses, prob.poses)
+
+
+def test_empty_window_round_trip(tmp_path):
+    prob = hipba.Problem(np.zeros((0, 7)), np.zeros((0, 3)), np.zeros(0, np.int32), np.zeros(0, np.int32),
+                         np.zeros((0, 2)), (1.0, 1.0, 0.0, 0.0))
+    for binary in (False, True):
+        path = str(tmp_path / ("e%d" % binary))
+        windows.save_window(path, prob, binary)
+        back = windows.load_window(path)
+        assert len(back.poses) == 0 and len(back.points) == 0 and len(back.obs_pose) == 0
+
+
+def test_bad_window_files_are_rejected(tmp_path):
+    p = tmp_path / "bad.txt"
+    p.write_text("not a window\n")
+    with pytest.raises(ValueError):
+        windows.load_window(str(p))
+    prob = scenes.small_window(7, n_frames=4, n_points=40)[0]
+    good = tmp_path / "good.bin"
+    windows.save_window(str(good), prob, binary=True)
+    data = good.read_bytes()
+    (tmp_path / "short.bin").write_bytes(data[:len(data) // 2])
+    with pytest.raises(ValueError):
+        windows.load_window(str(tmp_path / "short.bin"))
+    # an observation that points past the pose array
+    text = tmp_path / "range.txt"
+    windows.save_window(str(text), prob)
+    lines = text.read_text().split("\n")
+    k = lines.index("observations %d" % len(prob.obs_pose))
+    lines[k + 1] = "%d 0 1.0 1.0" % len(prob.poses)
+    text.write_text("\n".join(lines))
+    with pytest.raises(ValueError):
+        windows.load_window(str(text))
+
+
+class _RecordingOptimizer:
+    """Stands in for VO::Optimizer: shifts every window pose so that the splice is visible."""
+
+    def __init__(self):
+        self.calls = []
+
+    def optimize(self, map_, K):
+        self.calls.append(len(map_.frames_))
+        for f in map_.frames_:
+            f.pose_[4] += 100.0
+
+
+def _frame(i):
+    return vo.Frame([0, 0, 0, 1, float(i), 0, 0])
+
+
+def test_stage_trigger_and_splice_follow_the_reference():
+    # reference: src/frontend.cpp:65-84 with bundle_adjustment_window_ = 4 and a 30-frame map window
+    opt = _RecordingOptimizer()
+    stage = vo.BundleAdjustmentStage(opt, do_bundle_adjustment=True, bundle_adjustment_window=4)
+    m = vo.Map()
+    frames = [_frame(i) for i in range(10)]
+    for i in range(1, 10):
+        stage.step(m, frames[i - 1], frames[i], None)
+    # iterations 4 and 8 trigger (iterations_ starts at 1 and the step for frame i runs at iteration i)
+    assert opt.calls == [4, 8] and stage.num_optimizations_ == 2 and stage.iterations_ == 10
+    # step 1..3 append the previous frame's pose (frames 0,1,2); step 4: three poses < four window frames, so the
+    # trajectory is cleared and the window (frames 1..4, shifted) takes its place
+    # steps 5..7 append frames 4,5,6; step 8: erase the last 8 of 7+... -> cleared again, window frames 1..8
+    xs = [p[4] for p in stage.poses_]
+    assert xs[:8] == [201.0, 202.0, 203.0, 204.0, 105.0, 106.0, 107.0, 108.0]
+    assert xs[8:] == [108.0]  # step 9 appends frame 8 once more (frontend.cpp:81)
+
+
+def test_stage_without_bundle_adjustment_only_appends_previous_poses():
+    opt = _RecordingOptimizer()
+    stage = vo.BundleAdjustmentStage(opt)  # do_bundle_adjustment_ defaults to false (frontend.hpp:32)
+    m = vo.Map()
+    frames = [_frame(i) for i in range(6)]
+    for i in range(1, 6):
+        stage.step(m, frames[i - 1], frames[i], None)
+    assert opt.calls == [] and [p[4] for p in stage.poses_] == [0.0, 1.0, 2.0, 3.0, 4.0]
+
+
+def test_stage_splice_keeps_the_head_of_a_long_trajectory():
+    opt = _RecordingOptimizer()
+    stage = vo.BundleAdjustmentStage(opt, do_bundle_adjustment=True, bundle_adjustment_window=40)
+    m = vo.Map()
+    frames = [_frame(i) for i in range(42)]
+    for i in range(1, 42):
+        stage.step(m, frames[i - 1], frames[i], None)
+    # one trigger at iteration 40: 39 poses on record, the map holds its 30 newest frames (11..40)
+    assert opt.calls == [30]
+    xs = [p[4] for p in stage.poses_]
+    assert xs[:9] == [float(i) for i in range(9)]          # frames 0..8 survive
+    assert xs[9:39] == [100.0 + i for i in range(11, 41)]   # frames 9 and 10 fall out: the reference's off-by-two
+    assert xs[39:] == [140.0]
+
+
+def test_clean_map_drops_landmarks_of_expired_frames():
+    m = vo.Map()
+    old, new = vo.Frame(), vo.Frame()
+    lm_old, lm_both, lm_new = vo.MapPoint(), vo.MapPoint(), vo.MapPoint()
+    for lm in (lm_old, lm_both, lm_new):
+        m.insertLandmark(lm)
+    old.pushFeatureLeftWithLandmark((1, 1), lm_old)
+    old.pushFeatureLeftWithLandmark((2, 2), lm_both)
+    new.pushFeatureLeftWithLandmark((3, 3), lm_both)
+    new.pushFeatureLeftWithLandmark((4, 4), lm_new)
+    m.insertFrame(new)  # `old` is not in the window any more
+    assert m.cleanMap() == 1 and m.landmarks_ == [lm_both, lm_new]
+    assert m.cleanMap(keep_frames=(old,)) == 0
+
+
+def test_cpp_window_reader_accepts_python_files_without_a_gpu(tmp_path):
+    # ba_replay parses its inputs before it asks for a device: a malformed file fails with the parser's message
+    exe = os.path.join(LIB, "ba_replay")
+    if not os.path.exists(exe):
+        pytest.skip("ba_replay not built")
+    bad = tmp_path / "bad.txt"
+    bad.write_text("hipba-window 2 text\n")
+    r = subprocess.run([exe, str(bad)], capture_output=True, text=True)
+    assert r.returncode == 1 and "version 1" in r.stderr
+
+
+@pytest.mark.gpu
+def test_replay_cli_matches_python_solve(tmp_path):
+    exe = os.path.join(LIB, "ba_replay")
+    prob = scenes.small_window(11, n_frames=8, n_points=500)[0]
+    for binary in (False, True):
+        path = str(tmp_path / ("w%d" % binary))
+        windows.save_window(path, prob, binary)
+        out = tmp_path / ("out%d" % binary)
+        out.mkdir()
+        r = subprocess.run([exe, path, "--out-dir", str(out)] + (["--binary"] if binary else []),
+                           capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        solved = windows.load_window(str(out / (os.path.basename(path) + ".solved")))
+        ref = prob.copy()
+        s = hipba.Solver(0).solve(ref, hipba.reference_production_options(), log=False)
+        fields = r.stdout.split("\n")[0].split()
+        assert int(fields[fields.index("iterations") + 1]) == s["num_iterations"] - 1
+        assert float(fields[fields.index("final_cost") + 1]) == pytest.approx(s["final_cost"], rel=1e-9)
+        assert np.abs(solved.poses - ref.poses).max() < 1e-9
+        assert np.abs(solved.points - ref.points).max() < 1e-7
+
+
+@pytest.mark.gpu
+def test_replay_cli_batched_matches_one_by_one(tmp_path):
+    exe = os.path.join(LIB, "ba_replay")
+    paths = []
+    for i in range(3):
+        path = str(tmp_path / ("w%d.txt" % i))
+        windows.save_window(path, scenes.small_window(20 + i, n_frames=6, n_points=300)[0])
+        paths.append(path)
+    a = subprocess.run([exe] + paths, capture_output=True, text=True, timeout=120)
+    b = subprocess.run([exe] + paths + ["--batched"], capture_output=True, text=True, timeout=120)
+    assert a.returncode == 0 and b.returncode == 0, a.stderr + b.stderr
+    for la, lb in zip(a.stdout.split("\n")[:3], b.stdout.split("\n")[:3]):
+        fa, fb = la.split(), lb.split()
+        assert fa[fa.index("iterations") + 1] == fb[fb.index("iterations") + 1]
+        assert float(fa[fa.index("final_cost") + 1]) == pytest.approx(float(fb[fb.index("final_cost") + 1]), rel=1e-9)
+
+
+@pytest.mark.gpu
+def test_stage_demo_bundle_adjustment_reduces_drift_and_dumps_replayable_windows(tmp_path):
+    demo, replay = os.path.join(LIB, "ba_stage_demo"), os.path.join(LIB, "ba_replay")
+
+    def run(*args):
+        r = subprocess.run([demo, "--frames", "120", "--window", "20", "--seed", "7"] + list(args), capture_output=True,
+                           text=True, timeout=180)
+        assert r.returncode == 0, r.stderr
+        f = r.stdout.split()
+        return {k: float(f[f.index(k) + 1]) for k in ("trajectory_poses", "windows_solved", "landmarks_created",
+                                                       "landmarks_in_map", "mean_translation_error")}
+
+    dumps = tmp_path / "dumps"
+    dumps.mkdir()
+    none = run("--no-ba")
+    sync = run("--dump-dir", str(dumps))
+    asyn = run("--async")
+    assert none["windows_solved"] == 0 and sync["windows_solved"] == 5 and asyn["windows_solved"] == 5
+    # odometry noise accumulates without bundle adjustment; the windows pull it back (measured: 0.80 m -> 0.49 m)
+    assert sync["mean_translation_error"] < 0.8 * none["mean_translation_error"]
+    assert asyn["mean_translation_error"] < 0.85 * none["mean_translation_error"]
+    assert sync["landmarks_in_map"] < sync["landmarks_created"]  # cleanMap dropped the expired ones
+    files = sorted(os.listdir(dumps))
+    assert files == ["window_%06d.txt" % i for i in range(5)]
+    # a captured window replays, from Python and from the C++ tool, to the same optimum
+    w = windows.load_window(str(dumps / files[-1]))
+    assert w.pose_const[0] == 1 and w.pose_const[1:].sum() == 0 and len(w.poses) == 30
+    s = hipba.Solver(0).solve(w, hipba.reference_production_options(), log=False)
+    r = subprocess.run([replay, str(dumps / files[-1])], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    f = r.stdout.split()
+    assert float(f[f.index("final_cost") + 1]) == pytest.approx(s["final_cost"], rel=1e-9)
