@@ -189,7 +189,9 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    steps_done = summary["num_iterations"] - 1
+    # every trust-region step computed counts, also the one a convergence test ends on (which Ceres, and
+    # therefore the iteration log, does not list): each is one full pass of the hot path
+    steps_done = summary["num_linear_solves"]
 
     result = None
     if rank == 0:

@@ -131,7 +131,9 @@ typedef struct hipba_summary {
   double time_solve_s;             /* LM loop on the device */
   double time_total_s;
   int32_t linear_solver_used;      /* HIPBA_LINEAR_DENSE_CHOLESKY or HIPBA_LINEAR_PCG */
-  int32_t reserved;
+  int32_t num_linear_solves;       /* trust-region steps computed; Ceres does not log the step on which a
+                                      parameter/function-tolerance test ends the solve, so this can be
+                                      num_iterations (= log entries) rather than num_iterations - 1 */
   /* optional per-iteration log: caller-provided storage for iteration_log_capacity entries */
   hipba_iteration* iteration_log;
   int32_t iteration_log_capacity;

@@ -12,6 +12,8 @@ def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "kitti"
     if which == "kitti":
         probs = [scenes.kitti_like_window(1000)[0]]
+    elif which == "bal":
+        probs = [scenes.bal_scale(seed=3000, n_points=250_000)[0]]
     else:
         probs = [scenes.small_window(2000 + i)[0] for i in range(256)]
     dp = solver.upload(probs)

@@ -76,7 +76,7 @@ struct WinState {
   int solve_failed;     // set by the reduced solver of the current iteration
   int last_success_log; // log entry whose gradient norms are filled by the next linearisation
   int lin_iters;
-  int pad;
+  int num_linear_solves; // trust-region steps computed, the one a convergence test ends on included
   double radius;
   double decrease_factor;
   double x_cost;
@@ -124,11 +124,12 @@ struct DevP {
   const BlockDesc* blocks;
   const unsigned short* pairs;    // low byte = lane i, high byte = lane j, slot_i <= slot_j
   const RunDesc* runs;            // pair lists cut into runs of one destination (absent in staged mode)
-  // staged accumulation of the reduced matrix (one large window): slot of every pair in a buffer ordered
-  // by destination block, and the CSR of that order; null when fp64 atomics are used instead
-  const unsigned int* pair_slot;
+  // gathered accumulation of the reduced matrix (one large window): Y and W of every observation are kept
+  // in HBM, and every 6x6 block of S sums its products from a list of observation pairs ordered by
+  // destination block (CSR dest_start); null when fp64 atomics are used instead
+  const uint2* pair_obs;          // [n_pairs] (observation i, observation j), indices into the PM section
   const long long* dest_start;    // [n_dest + 1]
-  double* stage;                  // [36 * n_pairs]
+  double* yw;                     // [36 * n_pm_obs]: Y (18) then W (18) per observation
   long long n_dest;
   const WinDesc* wd;
   WinState* ws;
@@ -141,6 +142,7 @@ struct DevP {
   double* Vinv;     // [6*n_pm_points]  (V + D^2)^-1, symmetric packing
   double* gp;       // [3*n_pm_points]  scaled landmark gradient
   double* scale_p;  // [3*n_pm_points]
+  double* vg;       // [3*n_pm_points]  scale_p o (V^-1 g_p), gathered mode only
   double* S;        // packed upper block-triangular reduced matrices, 36 doubles per 6x6 block
   double* partial;  // [2 banks][kPartialStride * n_blocks]
   double* gpart;    // [2 * n_blk_pm] landmark gradient max / sum of squares per PM block

@@ -375,6 +375,114 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(DevP P, double* Amat, int ld
   }
 }
 
+// ---- the K = 128 steps of the panel chain ------------------------------------------------------------------
+// Same products as k_gemm_nt, for one panel (K = NB) and 64-row tiles:
+//   MODE 0: A(i,j) -= L(i,k) L(j,k)^T on 64x64 tiles,   MODE 1: L(i,k) = A(i,k) Linv(k)^T on 64x128 tiles.
+// These launches are short (a few hundred tiles, 4 MFLOP each) and sit on the critical path between two panel
+// factorisations; with one LDS stage in flight they were bound by eight back-to-back load latencies.  Here the
+// k-loop is fully unrolled and DEPTH stages of global loads are in flight at any time (all eight for the
+// 64x64 update, whose destination tile is fetched up front as well).
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void k_gemm_k128(DevP P, double* Amat, int ld, int i0, int j0, int kcol,
+                                                     const double* Linv) {
+  constexpr int TI = 64, TJ = MODE == 0 ? 64 : NB;
+  constexpr int LDA = TI + 16, LDB = TJ + 16;
+  constexpr int PA = TI / 16, PB = TJ / 16;    // doubles per thread and stage
+  constexpr int MI = TI / 32, MJ = TJ / 32;    // 16x16 sub-tiles per wave
+  constexpr int NCH = NB / KC;                 // 8 stages
+  constexpr int DEPTH = MODE == 0 ? 8 : 4;     // stages of global loads in flight
+  __shared__ __attribute__((aligned(16))) double sA[2][KC * LDA];
+  __shared__ __attribute__((aligned(16))) double sB[2][KC * LDB];
+  const int row0 = i0 * NB + blockIdx.x * TI;
+  const int col0 = MODE == 0 ? j0 * NB + blockIdx.y * TJ : 0;
+  if (MODE == 0 && col0 > row0 + TI - 1) return;  // wholly above the diagonal
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int lcol = t >> 4, lsub = t & 15;
+  const double* Ap = Amat + (long long)kcol * ld + row0;
+  const double* Bp = MODE == 0 ? Amat + (long long)kcol * ld + col0 : Linv;
+  const int ldb = MODE == 0 ? ld : NB;
+  double* Cp = MODE == 0 ? Amat + (long long)col0 * ld + row0 : Amat + (long long)kcol * ld + row0;
+
+  double2 ra[DEPTH][PA / 2], rb[DEPTH][PB / 2];
+#define K128_GLOAD(slot, chunk)                                                                                   \
+  {                                                                                                               \
+    const double2* a_ = reinterpret_cast<const double2*>(Ap + (long long)((chunk)*KC + lcol) * ld + lsub * PA);   \
+    const double2* b_ = reinterpret_cast<const double2*>(Bp + (long long)((chunk)*KC + lcol) * ldb + lsub * PB);  \
+    _Pragma("unroll") for (int m = 0; m < PA / 2; ++m) ra[slot][m] = a_[m];                                       \
+    _Pragma("unroll") for (int m = 0; m < PB / 2; ++m) rb[slot][m] = b_[m];                                       \
+  }
+#pragma unroll
+  for (int c = 0; c < DEPTH; ++c) K128_GLOAD(c, c);
+  // destination tile (MODE 0): fetched now, used after the last stage
+  double cold[MJ][MI][4];
+  if (MODE == 0) {
+#pragma unroll
+    for (int a = 0; a < MJ; ++a)
+#pragma unroll
+      for (int b = 0; b < MI; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          cold[a][b][r] = Cp[(long long)(wc * (TJ / 2) + a * 16 + (lane >> 4) + 4 * r) * ld + wr * (TI / 2) + b * 16 + (lane & 15)];
+  }
+  const bool live = P.ws[0].active && !P.ws[0].solve_failed;  // uniform; tested after the loads are on their way
+
+  v4d acc[MJ][MI];
+#pragma unroll
+  for (int a = 0; a < MJ; ++a)
+#pragma unroll
+    for (int b = 0; b < MI; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+  if (!live) return;
+
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int buf = c & 1, slot = c % DEPTH;
+    {
+      double2* a_ = reinterpret_cast<double2*>(&sA[buf][lcol * LDA + lsub * PA]);
+      double2* b_ = reinterpret_cast<double2*>(&sB[buf][lcol * LDB + lsub * PB]);
+#pragma unroll
+      for (int m = 0; m < PA / 2; ++m) a_[m] = ra[slot][m];
+#pragma unroll
+      for (int m = 0; m < PB / 2; ++m) b_[m] = rb[slot][m];
+    }
+    __syncthreads();  // stage c visible; everybody is past the reads of stage c - 2, which shared this buffer
+    if (c + DEPTH < NCH) K128_GLOAD(slot, c + DEPTH);
+#pragma unroll
+    for (int kk = 0; kk < KC / 4; ++kk) {
+      const int kr = kk * 4 + (lane >> 4);
+      double fa[MJ], fb[MI];
+#pragma unroll
+      for (int m = 0; m < MJ; ++m) fa[m] = sB[buf][kr * LDB + (lane & 15) + wc * (TJ / 2) + m * 16];
+#pragma unroll
+      for (int m = 0; m < MI; ++m) fb[m] = sA[buf][kr * LDA + (lane & 15) + wr * (TI / 2) + m * 16];
+#pragma unroll
+      for (int a = 0; a < MJ; ++a)
+#pragma unroll
+        for (int b = 0; b < MI; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
+    }
+  }
+#undef K128_GLOAD
+#pragma unroll
+  for (int a = 0; a < MJ; ++a) {
+#pragma unroll
+    for (int b = 0; b < MI; ++b) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int col = wc * (TJ / 2) + a * 16 + (lane >> 4) + 4 * r;
+        const int row = wr * (TI / 2) + b * 16 + (lane & 15);
+        double* dst = Cp + (long long)col * ld + row;
+        if (MODE == 0) {
+          *dst = cold[a][b][r] - acc[a][b][r];
+        } else {
+          *dst = acc[a][b][r];
+          // L^T goes to the (unused) upper triangle so that the backward substitution reads columns too
+          Amat[(long long)(row0 + row) * ld + kcol + col] = acc[a][b][r];
+        }
+      }
+    }
+  }
+}
+
 // ---- triangular solves with the blocked factor ------------------------------------------------------
 // forward step k: z_k = Linv_k b_k ; b_i -= L(i,k) z_k for every row block i > k
 __global__ __launch_bounds__(256) void k_trsv_fwd(DevP P, const double* A, int ld, int k, const double* Linv_all,
@@ -481,11 +589,11 @@ hipError_t big_solve_cholesky(const DevP& P, const BigWork& W, hipStream_t s) {
     for (int p = p0; p < p1; ++p) {
       hipLaunchKernelGGL(k_potrf_inv<0xff>, dim3(1), dim3(256), lds, s, P, W.A, ld, p, W.Linv, W.LinvT);
       if (nt - p - 1 > 0)
-        hipLaunchKernelGGL(k_gemm_nt<1>, dim3(nt - p - 1, 1), dim3(256), 0, s, P, W.A, ld, p + 1, 0, p * NB, NB,
+        hipLaunchKernelGGL(k_gemm_k128<1>, dim3(2 * (nt - p - 1), 1), dim3(256), 0, s, P, W.A, ld, p + 1, 0, p * NB,
                            (const double*)(W.Linv + (long long)p * NB * NB));
       if (p + 1 < p1)  // bring the block's remaining panel columns up to date with panel p (K = 128)
-        hipLaunchKernelGGL(k_gemm_nt<0>, dim3(nt - p - 1, p1 - p - 1), dim3(256), 0, s, P, W.A, ld, p + 1, p + 1, p * NB,
-                           NB, (const double*)nullptr);
+        hipLaunchKernelGGL(k_gemm_k128<0>, dim3(2 * (nt - p - 1), 2 * (p1 - p - 1)), dim3(256), 0, s, P, W.A, ld, p + 1,
+                           p + 1, p * NB, (const double*)nullptr);
     }
     const int rest = nt - p1;
     if (rest > 0)

@@ -385,14 +385,13 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   const int n_blk_cc = (int)blocks.size() - n_blk_pm - n_blk_vc;
   const int n_blocks = (int)blocks.size();
 
-  // ---- staged accumulation order (one large window): pairs sorted by destination block ----------------
+  // ---- gathered accumulation (one large window): observation pairs listed per destination block ---------
   // fp64 atomics into S run at ~1 TB/s of added bytes; beyond a few million 6x6 products it is faster to
-  // store every product once and sum per destination in a second pass.
-  std::vector<unsigned int> pair_slot;
+  // keep Y and W of every observation in HBM and let every block of S gather and sum its own products.
+  std::vector<uint2> pair_obs;
   std::vector<long long> dest_start;
   long long n_dest = 0;
-  const bool staged = nw == 1 && max_ncam > 20 && pairs.size() >= (size_t)2000000 && pairs.size() < 0xffffffffull &&
-                      pairs.size() * 288ull <= 64ull << 30;
+  const bool staged = nw == 1 && max_ncam > 20 && pairs.size() >= (size_t)2000000 && n_pm_obs < 0xffffffffll;
   if (staged) {
     const int ncam = wd[0].ncam;
     n_dest = (long long)ncam * (ncam + 1) / 2;
@@ -411,11 +410,16 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
     }
     for (long long i = 0; i < n_dest; ++i) dest_start[i + 1] += dest_start[i];
     std::vector<long long> cur(dest_start.begin(), dest_start.end() - 1);
-    pair_slot.resize(pairs.size());
+    pair_obs.resize((size_t)dest_start[n_dest]);
     for (const BlockDesc& d : blocks) {
       if (d.kind != 0) continue;
-      for (int q = 0; q < d.n_pairs; ++q) pair_slot[d.pair_begin + q] = (unsigned int)(cur[dest_of[d.pair_begin + q]]++);
+      for (int q = 0; q < d.n_pairs; ++q) {
+        const unsigned short pr = pairs[d.pair_begin + q];
+        pair_obs[cur[dest_of[d.pair_begin + q]]++] =
+            make_uint2((unsigned)(d.obs_begin + (pr & 0xff)), (unsigned)(d.obs_begin + (pr >> 8)));
+      }
     }
+    pairs.assign(8, kPairPad);  // the blocks themselves need no pair lists in this mode
   }
 
   // ---- atomic / LDS accumulation: each block's pair list grouped by destination block and cut into runs
@@ -561,7 +565,7 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   long long *d_cm_start, *d_pp_start;
   double *d_cm_uv, *d_obs_uv;
   BlockDesc* d_blocks; unsigned short* d_pairs; WinDesc* d_wd; RunDesc* d_runs;
-  unsigned int* d_pair_slot = nullptr; long long* d_dest_start = nullptr;
+  uint2* d_pair_obs = nullptr; long long* d_dest_start = nullptr;
   up.add(&P.poses[0], poses.size());
   up.add(&P.points[0], points.size());
   up.add(&d_pose_window, std::max<size_t>(pose_window.size(), 1));
@@ -578,7 +582,7 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   up.add(&d_pairs, std::max<size_t>(pairs.size(), 1));
   up.add(&d_wd, wd.size());
   up.add(&d_runs, std::max<size_t>(runs.size(), 1));
-  if (staged) { up.add(&d_pair_slot, pair_slot.size()); up.add(&d_dest_start, dest_start.size()); }
+  if (staged) { up.add(&d_pair_obs, pair_obs.size()); up.add(&d_dest_start, dest_start.size()); }
   const size_t upload_bytes = up.total;
   ArenaPlan work = up;  // continues after the uploaded region
   work.items.clear();
@@ -602,7 +606,7 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   work.add(&P.wsum, (size_t)8 * nw);
   work.add(&P.log, (size_t)std::max(log_cap, 1) * nw);
   work.add(&R->d_count, 4);
-  if (staged) work.add(&P.stage, 36 * pairs.size());
+  if (staged) { work.add(&P.yw, 36 * (size_t)n_pm_obs); work.add(&P.vg, 3 * npp); }
   char* big_base_dummy = nullptr;
   size_t big_bytes = 0;
   if (6 * max_ncam > kSmallMaxN) {
@@ -637,8 +641,8 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   P.cm_start = d_cm_start; P.cm_dp = d_cm_dp; P.cm_uv = d_cm_uv;
   P.obs_pose = d_obs_pose; P.obs_dp = d_obs_dp; P.obs_uv = d_obs_uv; P.pp_obs_start = d_pp_start;
   P.blocks = d_blocks; P.pairs = d_pairs; P.wd = d_wd; P.runs = d_runs;
-  P.pair_slot = d_pair_slot; P.dest_start = d_dest_start; P.n_dest = n_dest;
-  if (!staged) P.stage = nullptr;
+  P.pair_obs = d_pair_obs; P.dest_start = d_dest_start; P.n_dest = n_dest;
+  if (!staged) { P.yw = nullptr; P.vg = nullptr; }
 
   char* st = static_cast<char*>(h->staging);
   auto stage = [&](const void* dev_ptr, const void* src, size_t bytes) {
@@ -661,7 +665,7 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   stage(d_wd, wd.data(), wd.size() * sizeof(WinDesc));
   stage(d_runs, runs.data(), runs.size() * sizeof(RunDesc));
   if (staged) {
-    stage(d_pair_slot, pair_slot.data(), pair_slot.size() * 4);
+    stage(d_pair_obs, pair_obs.data(), pair_obs.size() * sizeof(uint2));
     stage(d_dest_start, dest_start.data(), dest_start.size() * 8);
   }
   hipStream_t s = h->stream;
@@ -807,6 +811,7 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
     sm.num_iterations = st.iteration + 1;
     sm.num_successful_steps = st.num_successful;
     sm.num_unsuccessful_steps = st.num_unsuccessful;
+    sm.num_linear_solves = st.num_linear_solves;
     sm.initial_cost = st.initial_cost;
     sm.final_cost = st.x_cost + st.fixed_cost;
     sm.fixed_cost = st.fixed_cost;

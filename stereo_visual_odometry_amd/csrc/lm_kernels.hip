@@ -190,6 +190,47 @@ __global__ __launch_bounds__(kBlock) void k_camera_blocks(DevP P, LmParams lm, i
   }
 }
 
+// reduced right-hand side, camera by camera: b_c -= sum over the camera's observations of variable landmarks of
+// Jc^T Jp V^-1 g_p (= Y g_p), with V^-1 g_p as k_point_schur left it in vg.  One workgroup and one writer per
+// pose: no atomics, fixed order.  Used with the gathered accumulation of S.
+__global__ __launch_bounds__(kBlock) void k_camera_rhs(DevP P, LmParams lm) {
+  __shared__ double red[6 * 4];
+  const int g = blockIdx.x;
+  const int c = P.slot_pose[g];
+  const int w = P.pose_window[c];
+  const WinState* st = P.ws + w;
+  if (!st->active) return;
+  const int sel = st->sel;
+  const CameraK K = P.wd[w].K;
+  double pose[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) pose[i] = P.poses[sel][7ll * c + i];
+  double sc[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) sc[i] = P.scale_c[6ll * g + i];
+  double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  const long long o1 = P.cm_start[g + 1];
+  for (long long o = P.cm_start[g] + threadIdx.x; o < o1; o += kBlock) {
+    const int pp = P.cm_dp[o];
+    if (pp >= P.n_pm_points) continue;  // constant landmark: nothing was eliminated
+    const double* p = P.points[sel] + 3ll * pp;
+    const double2 uv = reinterpret_cast<const double2*>(P.cm_uv)[o];
+    double r[2], Jc[12], Jp[6];
+    eval_obs<true>(K, lm, pose, p, uv.x, uv.y, sc, nullptr, r, Jc, Jp);  // landmark columns unscaled: vg carries scale_p
+    const double* tg = P.vg + 3ll * pp;
+    const double t0 = tg[0], t1 = tg[1], t2 = tg[2];
+    const double m0 = Jp[0] * t0 + Jp[1] * t1 + Jp[2] * t2;
+    const double m1 = Jp[3] * t0 + Jp[4] * t1 + Jp[5] * t2;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) acc[i] += Jc[i] * m0 + Jc[6 + i] * m1;
+  }
+  block_sum<6>(acc, red);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) P.b[6ll * g + i] -= acc[i];
+  }
+}
+
 // Jacobi scaling of the pose columns, computed once at iteration 0 from the unscaled blocks
 // (Ceres: scale = 1 / (1 + sqrt(squared column norm))), then folded into U and g.
 __global__ void k_make_scale_c(DevP P, int jacobi) {
@@ -405,8 +446,8 @@ __device__ __forceinline__ void pair_products(const unsigned short* pairs, const
 }
 
 // MODE 0: fp64 atomics straight into S, one workgroup per block.
-// MODE 2 (staged): every 6x6 product is written with plain stores to its precomputed slot of a staging
-//   buffer ordered by destination block; k_reduce_staged sums the slots (no atomics on S, fixed order).
+// MODE 2 (gathered): Y and W of every observation are written to HBM; k_schur_gather then lets every block
+//   of S sum its own products from a list of observation pairs (no atomics on S, fixed order).
 // MODE 1 / 3 (windows of at most kSmallMaxN/6 poses): `parts` workgroups per window, each walking every
 //   parts-th block of the window; b is accumulated in LDS and flushed once per workgroup, and so is the
 //   whole packed S when it fits (MODE 1; MODE 3 sends S to HBM with atomics).  A product is shared by two
@@ -520,9 +561,15 @@ __global__ __launch_bounds__(kBlock) void k_point_schur(DevP P, LmParams lm, int
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
           P.gp[3ll * pp + i] = gpv[i];
-          const double gu = gpv[i] / P.scale_p[3ll * pp + i];
+          const double sp = P.scale_p[3ll * pp + i];
+          const double gu = gpv[i] / sp;
           gmax = fmax(gmax, fabs(gu));
           g2 += gu * gu;
+          if (MODE == 2) {
+            // scale_p o (V^-1 g_p): what k_camera_rhs multiplies the unscaled landmark Jacobian with
+            const int r0 = i == 0 ? 0 : (i == 1 ? 1 : 2), r1 = i == 0 ? 1 : (i == 1 ? 3 : 4), r2 = i == 0 ? 2 : (i == 1 ? 4 : 5);
+            P.vg[3ll * pp + i] = sp * (Vi[r0] * gpv[0] + Vi[r1] * gpv[1] + Vi[r2] * gpv[2]);
+          }
         }
       }
       if (slot >= 0) {
@@ -537,12 +584,14 @@ __global__ __launch_bounds__(kBlock) void k_point_schur(DevP P, LmParams lm, int
           Y[3 * i + 1] = W[3 * i] * Vi[1] + W[3 * i + 1] * Vi[3] + W[3 * i + 2] * Vi[4];
           Y[3 * i + 2] = W[3 * i] * Vi[2] + W[3 * i + 1] * Vi[4] + W[3 * i + 2] * Vi[5];
         }
-        // b_c -= Y g_p
-        double* bdst = SMALL ? accB + 6 * slot : P.b + 6ll * (wd.cam_base + slot);
+        // b_c -= Y g_p (gathered mode leaves this to k_camera_rhs: one writer per pose instead of atomics)
+        if (MODE != 2) {
+          double* bdst = SMALL ? accB + 6 * slot : P.b + 6ll * (wd.cam_base + slot);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          const double v = Y[3 * i] * gpv[0] + Y[3 * i + 1] * gpv[1] + Y[3 * i + 2] * gpv[2];
-          atomic_add_f64(bdst + i, -v);
+          for (int i = 0; i < 6; ++i) {
+            const double v = Y[3 * i] * gpv[0] + Y[3 * i + 1] * gpv[1] + Y[3 * i + 2] * gpv[2];
+            atomic_add_f64(bdst + i, -v);
+          }
         }
       }
     }
@@ -568,22 +617,12 @@ __global__ __launch_bounds__(kBlock) void k_point_schur(DevP P, LmParams lm, int
 
     // phase 3: pair products (staged mode: every product to its own slot; otherwise run by run)
     if (MODE == 2) {
-      const int grp = t / kPairGroup, k = t - grp * kPairGroup;
-      if (grp < kPairGroups) {
-        const int bcol = k % 6, a0 = k / 6;
-        for (int q = grp; q < d.n_pairs; q += kPairGroups) {
-          const unsigned short pr = P.pairs[d.pair_begin + q];
-          const int i = pr & 0xff, j = pr >> 8;
-          const double* Yi = sYW + kYW * i;
-          const double* Wj = sYW + kYW * j + 18 + 3 * bcol;
-          const double w0 = Wj[0], w1 = Wj[1], w2 = Wj[2];
-          double* dst = P.stage + 36ll * P.pair_slot[d.pair_begin + q];
-#pragma unroll
-          for (int m = 0; m < 3; ++m) {
-            const int a = a0 + 2 * m;
-            dst[6 * a + bcol] = -(Yi[3 * a] * w0 + Yi[3 * a + 1] * w1 + Yi[3 * a + 2] * w2);
-          }
-        }
+      // Y and W of the block's observations go to HBM as they lie in LDS (coalesced); k_schur_gather forms the
+      // products.  Lanes without a variable pose carry no data, and no pair refers to them.
+      double* dst = P.yw + 36ll * d.obs_begin;
+      for (int idx = t; idx < 36 * d.n_obs; idx += kBlock) {
+        const int i = idx / 36;
+        dst[idx] = sYW[i * kYW + (idx - 36 * i)];
       }
     } else {
       double* Sbase = LDS_S ? accS : P.S + wd.S_off;
@@ -625,26 +664,52 @@ __global__ __launch_bounds__(kBlock) void k_point_schur(DevP P, LmParams lm, int
   HIPBA_TICK(7);
 }
 
-// staged mode: S(block d) += sum of its staged 6x6 contributions; 36 lanes per destination block,
-// seven destinations in flight per workgroup, contributions of one block are contiguous
-__global__ __launch_bounds__(kBlock) void k_reduce_staged(DevP P, long long n_dest) {
+// gathered mode: S(block d) -= sum over its observation pairs of Y_i W_j^T.  One wave per destination block,
+// sixteen pairs per batch: lanes 0-15 fetch the batch's pair records, the wave then loads the 16 x 36 operand
+// doubles (Y_i then W_j of each pair: 144-byte runs, nine loads per lane) and parks them in its LDS slice; lanes
+// 0-35 (lane e = 6 a + c owns entry (a, c)) read their row of Y and column of W back and accumulate.
+// Consecutive destinations share their row camera, so the Y rows mostly come from L2; the W rows are the HBM
+// traffic (144 B per pair).  Fixed summation order: S is reproducible run to run.
+constexpr int kGatherBatch = 16;
+__global__ __launch_bounds__(kBlock) void k_schur_gather(DevP P, long long n_dest) {
+  __shared__ double sOp[kBlock / 64][kGatherBatch * 36];
   if (!P.ws[0].active) return;
-  const int grp = threadIdx.x / 36, e = threadIdx.x - grp * 36;
-  if (grp >= 7) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int e = lane < 36 ? lane : 0, a = e / 6, c = e - 6 * a;
   double* S = P.S + P.wd[0].S_off;
-  for (long long d = (long long)blockIdx.x * 7 + grp; d < n_dest; d += (long long)gridDim.x * 7) {
+  const double* yw = P.yw;
+  double* op = sOp[wave];
+  for (long long d = (long long)blockIdx.x * (kBlock / 64) + wave; d < n_dest; d += (long long)gridDim.x * (kBlock / 64)) {
     const long long s0 = P.dest_start[d], s1 = P.dest_start[d + 1];
     if (s1 == s0) continue;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    long long s = s0;
-    for (; s + 4 <= s1; s += 4) {
-      a0 += P.stage[36 * s + e];
-      a1 += P.stage[36 * (s + 1) + e];
-      a2 += P.stage[36 * (s + 2) + e];
-      a3 += P.stage[36 * (s + 3) + e];
+    double acc = 0.0;
+    for (long long s = s0; s < s1; s += kGatherBatch) {
+      const int nb = (int)(s1 - s < kGatherBatch ? s1 - s : kGatherBatch);
+      uint2 pr = make_uint2(0u, 0u);
+      if (lane < nb) pr = P.pair_obs[s + lane];
+      double v[9];
+#pragma unroll
+      for (int m = 0; m < 9; ++m) {
+        const int q = lane + 64 * m;       // element of the batch: pair u, word k of [Y_i | W_j]
+        const int u = q / 36, k = q - 36 * u;
+        const unsigned oi = __shfl(pr.x, u), oj = __shfl(pr.y, u);
+        v[m] = u < nb ? yw[36ll * (k < 18 ? oi : oj) + k] : 0.0;
+      }
+      __builtin_amdgcn_wave_barrier();     // the previous batch's reads are done (same wave, program order)
+#pragma unroll
+      for (int m = 0; m < 9; ++m) op[lane + 64 * m] = v[m];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (lane < 36) {
+        for (int u = 0; u < nb; ++u) {
+          const double* yp = op + 36 * u + 3 * a;
+          const double* wp = op + 36 * u + 18 + 3 * c;
+          acc += yp[0] * wp[0] + yp[1] * wp[1] + yp[2] * wp[2];
+        }
+      }
     }
-    for (; s < s1; ++s) a0 += P.stage[36 * s + e];
-    S[36 * d + e] += (a0 + a1) + (a2 + a3);
+    if (lane < 36) S[36 * d + e] -= acc;
   }
 }
 
@@ -823,7 +888,7 @@ __global__ __launch_bounds__(kBlock) void k_window_init(DevP P, LmParams lm, int
   s.solve_failed = 0;
   s.last_success_log = 0;
   s.lin_iters = 0;
-  s.pad = 0;
+  s.num_linear_solves = 0;
   s.radius = lm.initial_radius;
   s.decrease_factor = 2.0;
   s.x_cost = acc[0];
@@ -927,6 +992,7 @@ __global__ __launch_bounds__(kBlock) void k_window_control(DevP P, LmParams lm, 
   }
 
   WinState s = *st;
+  s.num_linear_solves++;
   const int iter = s.iteration + 1;
   hipba_iteration it;
   it.iteration = iter; it.linear_solver_iterations = s.lin_iters;
@@ -1386,12 +1452,13 @@ hipError_t launch_point_schur(const DevP& P, const LmParams& lm, int small_ncam,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  if (P.stage) {
+  if (P.yw) {
     hipLaunchKernelGGL(k_point_schur<2>, dim3(P.n_blk_pm), dim3(kBlock), schur_lds_bytes(0, true), s, P, lm, 1);
     const long long n_dest = P.n_dest;
-    const long long want = (n_dest + 6) / 7;
-    const unsigned grid = (unsigned)(want < 16384 ? want : 16384);
-    hipLaunchKernelGGL(k_reduce_staged, dim3(grid), dim3(kBlock), 0, s, P, n_dest);
+    const long long want = (n_dest + kBlock / 64 - 1) / (kBlock / 64);
+    const unsigned grid = (unsigned)(want < 8192 ? want : 8192);
+    hipLaunchKernelGGL(k_schur_gather, dim3(grid), dim3(kBlock), 0, s, P, n_dest);
+    hipLaunchKernelGGL(k_camera_rhs, dim3(P.n_act_poses), dim3(kBlock), 0, s, P, lm);
   } else if (small_ncam > 0) {
     if (parts < 1) parts = 1;
     const size_t lds = schur_lds_bytes(small_ncam, false);

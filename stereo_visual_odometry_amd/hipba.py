@@ -72,7 +72,7 @@ class CSummary(C.Structure):
         ("num_active_poses", C.c_int32), ("num_active_points", C.c_int32),
         ("num_active_observations", C.c_int64),
         ("time_setup_s", C.c_double), ("time_solve_s", C.c_double), ("time_total_s", C.c_double),
-        ("linear_solver_used", C.c_int32), ("reserved", C.c_int32),
+        ("linear_solver_used", C.c_int32), ("num_linear_solves", C.c_int32),
         ("iteration_log", C.POINTER(CIteration)), ("iteration_log_capacity", C.c_int32), ("reserved2", C.c_int32),
     ]
 

@@ -340,7 +340,7 @@ def test_cpp_optimizer_adapter_through_ba_test_cli(golden):
 
 
 def test_staged_schur_accumulation_matches_oracle(solver, oracle):
-    # >= 2M 6x6 products switch the reduced-matrix accumulation from atomics to store-then-sum
+    # >= 2M 6x6 products switch the reduced-matrix accumulation from atomics to the per-block gather
     prob, _, _ = scenes.bal_scale(seed=21, grid=(10, 10), n_points=60000, depth_lo=5.0, depth_hi=30.0)
     g = prob.copy()
     s = solver.solve(g, hipba.default_options(max_num_iterations=6))
