@@ -12,11 +12,22 @@ def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "kitti"
     if which == "kitti":
         probs = [scenes.kitti_like_window(1000)[0]]
-    elif which == "bal":
+    elif which in ("bal", "potrf"):
         probs = [scenes.bal_scale(seed=3000, n_points=250_000)[0]]
     else:
         probs = [scenes.small_window(2000 + i)[0] for i in range(256)]
     dp = solver.upload(probs)
+    if which == "potrf":
+        ms = dp.time_kernel(hipba.KERNEL_REDUCED_SOLVE, 1)
+        n = 8
+        buf = (C.c_ulonglong * (8 * n))()
+        lib.hipba_debug_ticks.argtypes = [C.c_void_p, C.c_int]
+        lib.hipba_debug_ticks(buf, 8 * n)
+        t = np.frombuffer(buf, dtype=np.uint64).astype(np.int64)[:8]
+        print("reduced_solve %.2f ms; last panel factorisation in shader cycles: load %d, 8 tile steps %d, store %d, inverse %d" % (
+            ms, t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3]))
+        print("tile step 2: diagonal tile %d, panel %d, trailing (to end of step) ~%d" % (t[5] - t[7], t[6] - t[5], (t[2] - t[1]) // 8 - (t[6] - t[7])))
+        return
     ms = dp.time_kernel(hipba.KERNEL_POINT_SCHUR, 5)
     print("point_schur %.1f us" % (1e3 * ms))
     n = 4096

@@ -24,11 +24,15 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 // ---- workspace -----------------------------------------------------------------------------------
 static size_t rup(size_t v, size_t a) { return (v + a - 1) / a * a; }
 constexpr int kPcgScalars = 16;
+// leading dimension of the dense matrix: the padded order, one extra tile row for the right-hand side, and a
+// skew of kLdSkew doubles so that consecutive columns do not start on the same memory channel
+constexpr int kLdSkew = 16;
+static size_t dense_ld(size_t npad) { return npad + NB + kLdSkew; }
 
 size_t big_work_bytes(int n, int ncam) {
   const size_t npad = rup((size_t)n, NB);
   size_t b = 0;
-  b += rup(npad * npad * 8, 256);            // A
+  b += rup(dense_ld(npad) * (npad + NB) * 8, 256);  // A, with the extra tile row that carries the right-hand side
   b += 2 * rup((npad / NB) * NB * NB * 8, 256);  // Linv, LinvT
   b += rup(2 * npad * 8, 256);               // rhs, z
   b += rup((6 * npad + kPcgScalars + 3 * (size_t)ncam + 64) * 8, 256);  // pcg vectors + scalars + partials
@@ -40,7 +44,7 @@ void big_work_bind(BigWork& W, int n, int ncam, void* base) {
   const size_t npad = rup((size_t)n, NB);
   char* p = static_cast<char*>(base);
   W.n = n; W.npad = (int)npad;
-  W.A = reinterpret_cast<double*>(p); p += rup(npad * npad * 8, 256);
+  W.A = reinterpret_cast<double*>(p); p += rup(dense_ld(npad) * (npad + NB) * 8, 256);
   W.Linv = reinterpret_cast<double*>(p); p += rup((npad / NB) * NB * NB * 8, 256);
   W.LinvT = reinterpret_cast<double*>(p); p += rup((npad / NB) * NB * NB * 8, 256);
   W.rhs = reinterpret_cast<double*>(p); p += rup(2 * npad * 8, 256);
@@ -62,12 +66,22 @@ __global__ void k_unpack_lower(DevP P, double* A, int ld) {
   if (row >= col) A[(long long)col * ld + row] = v;
 }
 
-__global__ void k_pad_init(DevP P, double* A, double* rhs, int n, int ld) {
+// rows beyond n: identity on the padded diagonal, and b^T as row npad -- the first row of one extra tile row.
+// Factorising [S; b^T] row-wise like any other row block leaves z^T = (L^-1 b)^T in that row: the forward
+// substitution costs no launches of its own.
+__global__ void k_pad_init(DevP P, double* A, int n, int npad, int ld) {
   if (!P.ws[0].active) return;
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= ld) return;
+  if (col >= npad) return;
   for (int row = n; row < ld; ++row) A[(long long)col * ld + row] = (row == col) ? 1.0 : 0.0;
-  rhs[col] = col < n ? P.b[6ll * P.wd[0].cam_base + col] : 0.0;
+  if (col < n) A[(long long)col * ld + npad] = P.b[6ll * P.wd[0].cam_base + col];
+}
+
+// z = row npad of the factored matrix
+__global__ void k_extract_z(DevP P, const double* A, int npad, int ld, double* z) {
+  if (!P.ws[0].active || P.ws[0].solve_failed) return;
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col < npad) z[col] = A[(long long)col * ld + npad];
 }
 
 // ---- diagonal block: Cholesky + explicit inverse of the factor, one workgroup ------------------------
@@ -133,6 +147,7 @@ __global__ __launch_bounds__(256) void k_potrf_inv(DevP P, double* A, int ld, in
   int& fail = *reinterpret_cast<int*>(smem + kPotrfTiles * kTile);
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   double* Akk = A + (long long)k * NB * ld + (long long)k * NB;
+  HIPBA_CYCLES(0);
   // load the lower tiles: thread t carries element (row t & 15, column t >> 4) of every tile, so the 36
   // loads are independent and each wave reads 128-byte runs
   {
@@ -144,8 +159,10 @@ __global__ __launch_bounds__(256) void k_potrf_inv(DevP P, double* A, int ld, in
   }
   if (t == 0) fail = 0;
   __syncthreads();
+  HIPBA_CYCLES(1);
 
   for (int j = 0; j < NTL; ++j) {
+    if (j == 2) HIPBA_CYCLES(7);
     if (wave == 0 && (PH & 1)) {
       // (a) Cholesky and inverse of the 16x16 diagonal tile in registers: lane r holds row r, the
       // pivots and multipliers travel between lanes as wave-uniform scalars (v_readlane)
@@ -190,6 +207,7 @@ __global__ __launch_bounds__(256) void k_potrf_inv(DevP P, double* A, int ld, in
       }
     }
     __syncthreads();
+    if (j == 2) HIPBA_CYCLES(5);
     if (fail) break;
     // (b) panel below the diagonal tile: L(i,j) = A(i,j) * Linv(j,j)^T.  The product is formed transposed
     // (D = Linv * A^T) so that its store is lane-contiguous in the column-major tile.
@@ -199,6 +217,7 @@ __global__ __launch_bounds__(256) void k_potrf_inv(DevP P, double* A, int ld, in
       tile_store_t(Lt + ltile(i, j), acc, lane);
     }
     __syncthreads();
+    if (j == 2) HIPBA_CYCLES(6);
     // (c) trailing tiles: A(i2,j2) -= L(i2,j) L(j2,j)^T, again held transposed in the accumulator
     {
       int e = 0;
@@ -214,6 +233,7 @@ __global__ __launch_bounds__(256) void k_potrf_inv(DevP P, double* A, int ld, in
     }
     __syncthreads();
   }
+  HIPBA_CYCLES(2);
   if (fail) {
     if (t == 0) P.ws[0].solve_failed = 1;
     return;
@@ -228,6 +248,7 @@ __global__ __launch_bounds__(256) void k_potrf_inv(DevP P, double* A, int ld, in
         if (bi > bj || pr >= q) Akk[(long long)(TB * bj + q) * ld + TB * bi + pr] = Lt[ltile(bi, bj) + t];
   }
   __syncthreads();
+  HIPBA_CYCLES(3);
   // (d) X = L^-1 by tile columns; wave w takes columns w and 7 - w.  X^T tiles of the current column
   // live in the wave's scratch, the product Y^T in the (now free) diagonal tile slot (w, w).
   double* Linv = Linv_all + (long long)k * NB * NB;
@@ -270,11 +291,12 @@ __global__ __launch_bounds__(256) void k_potrf_inv(DevP P, double* A, int ld, in
       }
     }
   }
+  HIPBA_CYCLES(4);
 }
 
 // ---- fp64 matrix-core GEMM, C(i,j) (op)= sum_k A(i,k) B(j,k), column-major, 128x128 tiles ----------
 // MODE 0: update        A(i,j) -= sum over panel columns [kcol, kcol + K) of L(i,k) L(j,k)
-//                       (tile rows i0 + blockIdx.x, tile columns j0 + blockIdx.y, tiles with j > i skipped)
+//                       (1-D grid over the tiles (i0 + r, j0 + c), c <= r < m, plus row m in full)
 // MODE 1: panel solve   L(i,k)   = A(i,k) Linv(k)^T    (in place: the workgroup owns the tile; K = 128)
 //
 // The product is computed transposed (D[p][q] = C(i0+q, j0+p)) so that the 16 lanes sharing an
@@ -284,13 +306,31 @@ constexpr int LDT = 128 + 16;     // LDS row pitch (doubles): the two k-groups o
 
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void k_gemm_nt(DevP P, double* Amat, int ld, int i0, int j0, int kcol, int K,
-                                                 const double* Linv) {
+                                                 const double* Linv, long long Linv_or_m) {
   __shared__ __attribute__((aligned(16))) double sA[2][KC * LDT];  // i-tile
   __shared__ __attribute__((aligned(16))) double sB[2][KC * LDT];  // j-tile
   if (!P.ws[0].active || P.ws[0].solve_failed) return;
-  const int ti = i0 + blockIdx.x;
-  const int tj = j0 + blockIdx.y;
-  if (MODE == 0 && tj > ti) return;
+  int ti, tj;
+  if (MODE == 0) {
+    // One workgroup per tile of the lower triangle of an m x m tile grid (row by row), then one per tile of an
+    // extra full row m (the right-hand side): a 1-D grid without idle workgroups.  Workgroups go to the eight
+    // XCDs round-robin by index, so every XCD gets the same number of tiles whatever m is (a 2-D grid with
+    // early exits above the diagonal left some XCDs up to 17 % more tiles than others for odd widths).
+    const int m = (int)Linv_or_m;
+    const int id = blockIdx.x, tri = m * (m + 1) / 2;
+    int r, c;
+    if (id < tri) {
+      r = (int)((sqrtf(8.0f * id + 1.0f) - 1.0f) * 0.5f);
+      while (r * (r + 1) / 2 > id) --r;
+      while ((r + 1) * (r + 2) / 2 <= id) ++r;
+      c = id - r * (r + 1) / 2;
+    } else {
+      r = m; c = id - tri;
+    }
+    ti = i0 + r; tj = j0 + c;
+  } else {
+    ti = i0 + blockIdx.x; tj = j0 + blockIdx.y;
+  }
   const double* Ap = Amat + (long long)kcol * ld + (long long)ti * NB;   // rows of tile i, panel columns
   const double* Bp;
   int ldb;
@@ -483,43 +523,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k128(DevP P, double* Amat, int 
   }
 }
 
-// ---- triangular solves with the blocked factor ------------------------------------------------------
-// forward step k: z_k = Linv_k b_k ; b_i -= L(i,k) z_k for every row block i > k
-__global__ __launch_bounds__(256) void k_trsv_fwd(DevP P, const double* A, int ld, int k, const double* Linv_all,
-                                                  double* rhs, double* z) {
-  __shared__ double bk[NB];
-  __shared__ double zk[NB];
-  __shared__ double part[2][NB];
-  if (!P.ws[0].active || P.ws[0].solve_failed) return;
-  const int t = threadIdx.x;
-  const double* Linv = Linv_all + (long long)k * NB * NB;
-  if (t < NB) bk[t] = rhs[k * NB + t];
-  __syncthreads();
-  {
-    const int r = t & (NB - 1), h = t >> 7;  // two threads per row, each half of the columns
-    double s = 0.0;
-    for (int c = h * (NB / 2); c < (h + 1) * (NB / 2); ++c) s += Linv[c * NB + r] * bk[c];
-    part[h][r] = s;
-  }
-  __syncthreads();
-  if (t < NB) zk[t] = part[0][t] + part[1][t];
-  __syncthreads();
-  if (blockIdx.x == 0) {
-    if (t < NB) z[k * NB + t] = zk[t];
-    return;
-  }
-  const int i = k + blockIdx.x;
-  const double* Lik = A + (long long)k * NB * ld + (long long)i * NB;
-  {
-    const int r = t & (NB - 1), h = t >> 7;
-    double s = 0.0;
-    for (int c = h * (NB / 2); c < (h + 1) * (NB / 2); ++c) s += Lik[(long long)c * ld + r] * zk[c];
-    part[h][r] = s;
-  }
-  __syncthreads();
-  if (t < NB) rhs[i * NB + t] -= part[0][t] + part[1][t];
-}
-
+// ---- backward substitution with the blocked factor (the forward one happens inside the factorisation) ----
 // backward step k: y_k = Linv_k^T z_k ; z_j -= L(k,j)^T y_k for every row block j < k.  L(k,j)^T is read
 // from the upper triangle (written by the panel solve), so the access pattern mirrors the forward step.
 __global__ __launch_bounds__(256) void k_trsv_bwd(DevP P, const double* A, int ld, int k, const double* LinvT_all,
@@ -572,10 +576,11 @@ hipError_t big_solve_cholesky(const DevP& P, const BigWork& W, hipStream_t s) {
                               160 * 1024);
     attr_done = true;
   }
-  const int n = W.n, ld = W.npad, nt = ld / NB;
+  const int n = W.n, npad = W.npad, nt = npad / NB;
+  const int ld = (int)dense_ld(npad);  // one extra tile row: b^T rides along as row npad (see k_pad_init)
   const int ncam = n / 6;
   hipLaunchKernelGGL(k_unpack_lower, dim3((ncam * 36 + 255) / 256, ncam), dim3(256), 0, s, P, W.A, ld);
-  hipLaunchKernelGGL(k_pad_init, dim3((ld + 255) / 256), dim3(256), 0, s, P, W.A, W.rhs, n, ld);
+  hipLaunchKernelGGL(k_pad_init, dim3((npad + 255) / 256), dim3(256), 0, s, P, W.A, n, npad, ld);
   const size_t lds = (size_t)kPotrfTiles * kTile * 8 + 64;
   // Two-level right-looking factorisation.  Panels of 128 columns are grouped in blocks of kOuter
   // panels.  Inside a block a freshly factored panel only updates the block's remaining panel columns
@@ -583,27 +588,26 @@ hipError_t big_solve_cholesky(const DevP& P, const BigWork& W, hipStream_t s) {
   // K = kOuter * 128, which divides the read-modify-write traffic of the trailing tiles by kOuter.
   // (Overlapping that update with the next block's panel chain on a second stream was measured and
   // lost 5 %: the panel kernels then queue behind 50 us trailing-update workgroups.)
+  // Row tiles run to nt inclusive: tile row nt is the right-hand side.
   constexpr int kOuter = 8;
   for (int p0 = 0; p0 < nt; p0 += kOuter) {
     const int p1 = p0 + kOuter < nt ? p0 + kOuter : nt;
     for (int p = p0; p < p1; ++p) {
       hipLaunchKernelGGL(k_potrf_inv<0xff>, dim3(1), dim3(256), lds, s, P, W.A, ld, p, W.Linv, W.LinvT);
-      if (nt - p - 1 > 0)
-        hipLaunchKernelGGL(k_gemm_k128<1>, dim3(2 * (nt - p - 1), 1), dim3(256), 0, s, P, W.A, ld, p + 1, 0, p * NB,
-                           (const double*)(W.Linv + (long long)p * NB * NB));
+      hipLaunchKernelGGL(k_gemm_k128<1>, dim3(2 * (nt - p - 1) + 1, 1), dim3(256), 0, s, P, W.A, ld, p + 1, 0, p * NB,
+                         (const double*)(W.Linv + (long long)p * NB * NB));
       if (p + 1 < p1)  // bring the block's remaining panel columns up to date with panel p (K = 128)
-        hipLaunchKernelGGL(k_gemm_k128<0>, dim3(2 * (nt - p - 1), 2 * (p1 - p - 1)), dim3(256), 0, s, P, W.A, ld, p + 1,
-                           p + 1, p * NB, (const double*)nullptr);
+        hipLaunchKernelGGL(k_gemm_k128<0>, dim3(2 * (nt - p - 1) + 1, 2 * (p1 - p - 1)), dim3(256), 0, s, P, W.A, ld,
+                           p + 1, p + 1, p * NB, (const double*)nullptr);
     }
     const int rest = nt - p1;
     if (rest > 0)
-      hipLaunchKernelGGL(k_gemm_nt<0>, dim3(rest, rest), dim3(256), 0, s, P, W.A, ld, p1, p1, p0 * NB, (p1 - p0) * NB,
-                         (const double*)nullptr);
+      hipLaunchKernelGGL(k_gemm_nt<0>, dim3(rest * (rest + 1) / 2 + rest), dim3(256), 0, s, P, W.A, ld, p1, p1, p0 * NB,
+                         (p1 - p0) * NB, (const double*)nullptr, (long long)rest);
   }
-  double* z = W.rhs + ld;
-  for (int k = 0; k < nt; ++k)
-    hipLaunchKernelGGL(k_trsv_fwd, dim3(nt - k), dim3(256), 0, s, P, W.A, ld, k, W.Linv, W.rhs, z);
-  double* y = W.rhs;  // rhs is dead after the forward sweep
+  double* z = W.rhs + npad;
+  hipLaunchKernelGGL(k_extract_z, dim3((npad + 255) / 256), dim3(256), 0, s, P, (const double*)W.A, npad, ld, z);
+  double* y = W.rhs;
   for (int k = nt - 1; k >= 0; --k)
     hipLaunchKernelGGL(k_trsv_bwd, dim3(k + 1), dim3(256), 0, s, P, W.A, ld, k, W.LinvT, z, y);
   hipLaunchKernelGGL(k_store_solution, dim3((n + 255) / 256), dim3(256), 0, s, P, y, n);

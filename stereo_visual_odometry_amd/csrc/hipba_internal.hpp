@@ -34,7 +34,8 @@ hipError_t launch_residual_jacobian(const CameraK& K, const LmParams& lm, int ap
 struct BigWork {
   int n = 0;           // 6 * ncam
   int npad = 0;        // n rounded up to the factorisation panel width
-  double* A = nullptr;     // [npad * npad] column-major, lower triangle holds S then its Cholesky factor
+  double* A = nullptr;     // [(npad + NB)^2] column-major, lower triangle holds S then its Cholesky factor;
+                           // row npad carries b^T, then z^T = (L^-1 b)^T
   double* Linv = nullptr;  // [npad/NB][NB*NB] inverses of the diagonal blocks of L
   double* LinvT = nullptr; // the same blocks transposed (backward substitution reads them by rows)
   double* rhs = nullptr;   // [npad]
@@ -51,3 +52,15 @@ hipError_t big_solve_cholesky(const DevP& P, const BigWork& W, hipStream_t s);
 hipError_t big_solve_pcg(const DevP& P, const BigWork& W, int max_iter, double tol, hipStream_t s);
 
 }  // namespace hipba
+
+// development aid (-DHIPBA_PHASE_TIMING): 100 MHz timestamps of workgroup phases, read back by hipba_debug_ticks
+#ifdef HIPBA_PHASE_TIMING
+namespace hipba { extern __device__ unsigned long long g_ticks[8 * 4096]; }
+#define HIPBA_TICK(i) \
+  if (threadIdx.x == 0 && blockIdx.x < 4096) hipba::g_ticks[8 * blockIdx.x + (i)] = wall_clock64()
+#define HIPBA_CYCLES(i) \
+  if (threadIdx.x == 0 && blockIdx.x < 4096) hipba::g_ticks[8 * blockIdx.x + (i)] = clock64()
+#else
+#define HIPBA_TICK(i)
+#define HIPBA_CYCLES(i)
+#endif

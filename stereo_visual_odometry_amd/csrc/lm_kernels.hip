@@ -15,6 +15,7 @@
 #include <cfloat>
 
 #include "ba_device.hpp"
+#include "hipba_internal.hpp"
 
 namespace hipba {
 
@@ -356,15 +357,7 @@ __global__ void k_init_reduced(DevP P, LmParams lm, int owner) {
 // LDS_ACC: the window's whole packed S and b fit in LDS; accumulate there and flush once.
 // ------------------------------------------------------------------------------------------
 #ifdef HIPBA_PHASE_TIMING
-// development aid: 100 MHz timestamps of workgroup phases, read back by hipba_debug_ticks
 __device__ unsigned long long g_ticks[8 * 4096];
-#define HIPBA_TICK(i) \
-  if (threadIdx.x == 0 && blockIdx.x < 4096) g_ticks[8 * blockIdx.x + (i)] = wall_clock64()
-#define HIPBA_CYCLES(i) \
-  if (threadIdx.x == 0 && blockIdx.x < 4096) g_ticks[8 * blockIdx.x + (i)] = clock64()
-#else
-#define HIPBA_TICK(i)
-#define HIPBA_CYCLES(i)
 #endif
 
 constexpr int kPairGroup = 12;
