@@ -93,7 +93,7 @@ __global__ void k_extract_z(DevP P, const double* A, int npad, int ld, double* z
 constexpr int TB = 16;
 constexpr int NTL = NB / TB;                      // 8 tile rows
 constexpr int kTile = TB * TB;                    // doubles per tile
-constexpr int kPotrfTiles = NTL * (NTL + 1) / 2 + NTL + 4 * NTL;  // L tiles + diagonal inverses + per-wave X^T tiles
+constexpr int kPotrfTiles = NTL * (NTL + 1) / 2 + NTL;  // L tiles + diagonal inverses
 
 __device__ __forceinline__ int ltile(int bi, int bj) { return (bi * (bi + 1) / 2 + bj) * kTile; }
 
@@ -143,7 +143,6 @@ __global__ __launch_bounds__(256) void k_potrf_inv(DevP P, double* A, int ld, in
   if (!P.ws[0].active || P.ws[0].solve_failed) return;
   double* Lt = smem;                                   // 36 tiles
   double* Dinv = smem + (NTL * (NTL + 1) / 2) * kTile;   // 8 tiles
-  double* XT = Dinv + NTL * kTile;                     // 4 waves x 8 tiles
   int& fail = *reinterpret_cast<int*>(smem + kPotrfTiles * kTile);
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   double* Akk = A + (long long)k * NB * ld + (long long)k * NB;
@@ -249,12 +248,12 @@ __global__ __launch_bounds__(256) void k_potrf_inv(DevP P, double* A, int ld, in
   }
   __syncthreads();
   HIPBA_CYCLES(3);
-  // (d) X = L^-1 by tile columns; wave w takes columns w and 7 - w.  X^T tiles of the current column
-  // live in the wave's scratch, the product Y^T in the (now free) diagonal tile slot (w, w).
+  // (d) X = L^-1 by tile columns; wave w takes columns w and 7 - w.  The tiles of the current column stay in
+  // registers: an accumulator tile D(p, q) sits in exactly the lanes and registers the B operand of the next
+  // product wants (k = p, n = q), so X(tt, j) feeds y += L(i, tt) X(tt, j) and Y feeds X(i, j) = -Dinv(i) Y
+  // without a trip through LDS.
   double* Linv = Linv_all + (long long)k * NB * NB;
   double* LinvT = LinvT_all + (long long)k * NB * NB;
-  double* myXT = XT + wave * NTL * kTile;
-  double* YT = Lt + ltile(wave, wave);
   for (int pass = 0; pass < 2 && (PH & 8); ++pass) {
     const int j = pass == 0 ? wave : NTL - 1 - wave;
     // tiles above the diagonal are zero
@@ -266,28 +265,34 @@ __global__ __launch_bounds__(256) void k_potrf_inv(DevP P, double* A, int ld, in
         LinvT[(long long)(TB * i + (lane >> 4) + 4 * r) * NB + TB * j + (lane & 15)] = 0.0;
       }
     }
-    {
-      const v4d d = tile_load(Dinv + j * kTile, lane);
-      tile_store_t(myXT + j * kTile, d, lane);
+    v4d xs[NTL];  // X(j + rel, j), rel = 0 .. 7 - j
+    xs[0] = tile_load(Dinv + j * kTile, lane);
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-      {
-        Linv[(long long)(TB * j + (lane & 15)) * NB + TB * j + (lane >> 4) + 4 * r] = d[r];
-        LinvT[(long long)(TB * j + (lane >> 4) + 4 * r) * NB + TB * j + (lane & 15)] = d[r];
-      }
-    }
-    for (int i = j + 1; i < NTL; ++i) {
-      v4d y = (v4d){0.0, 0.0, 0.0, 0.0};
-      for (int tt = j; tt < i; ++tt) y = mfma_tile<false>(Lt + ltile(i, tt), myXT + tt * kTile, y, lane);
-      tile_store_t(YT, y, lane);
-      v4d x = (v4d){0.0, 0.0, 0.0, 0.0};
-      x = mfma_tile<true>(Dinv + i * kTile, YT, x, lane);
-      tile_store_t(myXT + i * kTile, x, lane);
+    for (int rel = 0; rel < NTL; ++rel) {
+      const int i = j + rel;
+      if (i < NTL) {
+        if (rel > 0) {
+          v4d y = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-      {
-        Linv[(long long)(TB * j + (lane & 15)) * NB + TB * i + (lane >> 4) + 4 * r] = x[r];
-        LinvT[(long long)(TB * i + (lane >> 4) + 4 * r) * NB + TB * j + (lane & 15)] = x[r];
+          for (int rt = 0; rt < rel; ++rt) {
+            const double* M = Lt + ltile(i, j + rt);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+              y = __builtin_amdgcn_mfma_f64_16x16x4f64(M[(kk * 4 + (lane >> 4)) * TB + (lane & 15)], xs[rt][kk], y, 0, 0, 0);
+          }
+          v4d x = (v4d){0.0, 0.0, 0.0, 0.0};
+          const double* Di = Dinv + i * kTile;
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk)
+            x = __builtin_amdgcn_mfma_f64_16x16x4f64(-Di[(kk * 4 + (lane >> 4)) * TB + (lane & 15)], y[kk], x, 0, 0, 0);
+          xs[rel] = x;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+        {
+          Linv[(long long)(TB * j + (lane & 15)) * NB + TB * i + (lane >> 4) + 4 * r] = xs[rel][r];
+          LinvT[(long long)(TB * i + (lane >> 4) + 4 * r) * NB + TB * j + (lane & 15)] = xs[rel][r];
+        }
       }
     }
   }
@@ -511,14 +516,40 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k128(DevP P, double* Amat, int 
         const int col = wc * (TJ / 2) + a * 16 + (lane >> 4) + 4 * r;
         const int row = wr * (TI / 2) + b * 16 + (lane & 15);
         double* dst = Cp + (long long)col * ld + row;
-        if (MODE == 0) {
-          *dst = cold[a][b][r] - acc[a][b][r];
-        } else {
-          *dst = acc[a][b][r];
-          // L^T goes to the (unused) upper triangle so that the backward substitution reads columns too
-          Amat[(long long)(row0 + row) * ld + kcol + col] = acc[a][b][r];
-        }
+        if (MODE == 0) *dst = cold[a][b][r] - acc[a][b][r];
+        else *dst = acc[a][b][r];
       }
+    }
+  }
+  if (MODE == 1) {
+    // L^T goes to the (unused) upper triangle so that the backward substitution reads columns too.  In the
+    // accumulators consecutive lanes hold consecutive ROWS of L; each wave turns its 32 x 64 block around in LDS,
+    // 32 columns at a time, so that consecutive lanes write consecutive columns (256-byte runs, not 8-byte ones).
+    constexpr int TP = 33;                      // staging pitch (doubles): odd, no bank conflicts on the way back
+    __syncthreads();                            // every wave is done reading the last stage
+    double* stg = &sB[0][0] + wave * 32 * TP;   // 4 x 8.4 KB inside sB
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int a2 = 0; a2 < 2; ++a2) {
+        const int a = 2 * half + a2;
+#pragma unroll
+        for (int b = 0; b < MI; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            stg[(b * 16 + (lane & 15)) * TP + a2 * 16 + (lane >> 4) + 4 * r] = acc[a][b][r];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // 32 rows x 32 columns: lanes 0-31 take the columns of row rr, lanes 32-63 those of row rr + 1
+#pragma unroll
+      for (int rr = 0; rr < 32; rr += 2) {
+        const int rl = rr + (lane >> 5), cl = lane & 31;
+        Amat[(long long)(row0 + wr * 32 + rl) * ld + kcol + wc * 64 + half * 32 + cl] = stg[rl * TP + cl];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
   }
 }

@@ -264,6 +264,8 @@ def test_sharded_solve_equals_unsharded(oracle):
     stages through host memory.  Exercises the reduce/decide kernel modes and the owner rule without RCCL."""
     import ctypes as C
     import torch
+    torch.cuda.init()  # the two rank threads would otherwise race through torch's lazy device initialisation
+    torch.cuda.synchronize()
     prob, _, _ = scenes.bal_scale(seed=5, grid=(6, 7), n_points=6000, depth_lo=5.0, depth_hi=25.0)
     opts = lambda: hipba.default_options(max_num_iterations=6)
     ref = prob.copy()
