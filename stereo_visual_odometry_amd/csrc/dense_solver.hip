@@ -14,6 +14,8 @@
 // npad, a multiple of the 128-wide panel), padded with an identity block.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "hipba_internal.hpp"
 
 namespace hipba {
@@ -144,6 +146,7 @@ __global__ __launch_bounds__(256) void k_potrf_inv(DevP P, double* A, int ld, in
   double* Lt = smem;                                   // 36 tiles
   double* Dinv = smem + (NTL * (NTL + 1) / 2) * kTile;   // 8 tiles
   int& fail = *reinterpret_cast<int*>(smem + kPotrfTiles * kTile);
+  double* rdiag = smem + kPotrfTiles * kTile + 8;        // [NB] reciprocals of the factor's diagonal
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   double* Akk = A + (long long)k * NB * ld + (long long)k * NB;
   HIPBA_CYCLES(0);
@@ -163,8 +166,9 @@ __global__ __launch_bounds__(256) void k_potrf_inv(DevP P, double* A, int ld, in
   for (int j = 0; j < NTL; ++j) {
     if (j == 2) HIPBA_CYCLES(7);
     if (wave == 0 && (PH & 1)) {
-      // (a) Cholesky and inverse of the 16x16 diagonal tile in registers: lane r holds row r, the
-      // pivots and multipliers travel between lanes as wave-uniform scalars (v_readlane)
+      // (a) Cholesky of the 16x16 diagonal tile in registers: lane r holds row r, the pivots and multipliers
+      // travel between lanes as wave-uniform scalars (v_readlane).  The tile's inverse is not needed inside
+      // the loop (the panel below is solved by substitution) and is formed for all eight tiles at once later.
       double* D = Lt + ltile(j, j);
       const int r = lane & 15;
       double x[TB], rinv[TB];
@@ -186,34 +190,35 @@ __global__ __launch_bounds__(256) void k_potrf_inv(DevP P, double* A, int ld, in
       }
       if (bad) {
         if (lane == 0) fail = 1;
-      } else {
-        // lane c owns column c of the inverse (forward substitution; entries above the diagonal come out 0)
-        double y[TB];
+      } else if (lane < TB) {
 #pragma unroll
-        for (int i = 0; i < TB; ++i) {
-          double acc = (i == r) ? 1.0 : 0.0;
-#pragma unroll
-          for (int tt = 0; tt < i; ++tt) acc -= bcast_lane(x[tt], i) * y[tt];
-          y[i] = acc * rinv[i];
-        }
-        if (lane < TB) {
-#pragma unroll
-          for (int c = 0; c < TB; ++c) {
-            if (c <= r) D[c * TB + r] = x[c];
-            Dinv[j * kTile + r * TB + c] = y[c];   // lane r holds column r of the inverse
-          }
+        for (int c = 0; c < TB; ++c) {
+          if (c <= r) D[c * TB + r] = x[c];
+          if (c == r) rdiag[j * TB + c] = rinv[c];
         }
       }
     }
     __syncthreads();
     if (j == 2) HIPBA_CYCLES(5);
     if (fail) break;
-    // (b) panel below the diagonal tile: L(i,j) = A(i,j) * Linv(j,j)^T.  The product is formed transposed
-    // (D = Linv * A^T) so that its store is lane-contiguous in the column-major tile.
-    for (int i = j + 1 + wave; i < NTL && (PH & 2); i += 4) {
-      v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
-      acc = mfma_tile<false>(Dinv + j * kTile, Lt + ltile(i, j), acc, lane);
-      tile_store_t(Lt + ltile(i, j), acc, lane);
+    // (b) panel below the diagonal tile: L(i,j) = A(i,j) L(j,j)^-T, one lane per row, forward substitution with
+    // the diagonal tile read from LDS (every lane reads the same words: broadcasts)
+    if (t < TB * (NTL - 1 - j) && (PH & 2)) {
+      double* T = Lt + ltile(j + 1 + (t >> 4), j) + (t & 15);
+      const double* D = Lt + ltile(j, j);
+      const double* ri = rdiag + j * TB;
+      double x[TB];
+#pragma unroll
+      for (int c = 0; c < TB; ++c) x[c] = T[c * TB];
+#pragma unroll
+      for (int c = 0; c < TB; ++c) {
+        double v = x[c];
+#pragma unroll
+        for (int t2 = 0; t2 < c; ++t2) v -= x[t2] * D[t2 * TB + c];
+        x[c] = v * ri[c];
+      }
+#pragma unroll
+      for (int c = 0; c < TB; ++c) T[c * TB] = x[c];
     }
     __syncthreads();
     if (j == 2) HIPBA_CYCLES(6);
@@ -245,6 +250,23 @@ __global__ __launch_bounds__(256) void k_potrf_inv(DevP P, double* A, int ld, in
 #pragma unroll
       for (int bj = 0; bj <= bi; ++bj)
         if (bi > bj || pr >= q) Akk[(long long)(TB * bj + q) * ld + TB * bi + pr] = Lt[ltile(bi, bj) + t];
+  }
+  // inverses of the eight diagonal tiles, all at once: 16 lanes per tile, lane r forms column r by forward
+  // substitution with the tile read from LDS
+  if (wave < 2) {
+    const int tl = wave * 4 + (lane >> 4), r = lane & 15;
+    const double* D = Lt + ltile(tl, tl);
+    const double* ri = rdiag + tl * TB;
+    double y[TB];
+#pragma unroll
+    for (int i = 0; i < TB; ++i) {
+      double acc = (i == r) ? 1.0 : 0.0;
+#pragma unroll
+      for (int tt = 0; tt < i; ++tt) acc -= D[tt * TB + i] * y[tt];
+      y[i] = acc * ri[i];
+    }
+#pragma unroll
+    for (int c = 0; c < TB; ++c) Dinv[tl * kTile + r * TB + c] = y[c];
   }
   __syncthreads();
   HIPBA_CYCLES(3);
@@ -612,7 +634,7 @@ hipError_t big_solve_cholesky(const DevP& P, const BigWork& W, hipStream_t s) {
   const int ncam = n / 6;
   hipLaunchKernelGGL(k_unpack_lower, dim3((ncam * 36 + 255) / 256, ncam), dim3(256), 0, s, P, W.A, ld);
   hipLaunchKernelGGL(k_pad_init, dim3((npad + 255) / 256), dim3(256), 0, s, P, W.A, n, npad, ld);
-  const size_t lds = (size_t)kPotrfTiles * kTile * 8 + 64;
+  const size_t lds = (size_t)kPotrfTiles * kTile * 8 + 64 + NB * 8;
   // Two-level right-looking factorisation.  Panels of 128 columns are grouped in blocks of kOuter
   // panels.  Inside a block a freshly factored panel only updates the block's remaining panel columns
   // (narrow updates, K = 128); the rest of the trailing matrix is updated once per block with
@@ -620,7 +642,7 @@ hipError_t big_solve_cholesky(const DevP& P, const BigWork& W, hipStream_t s) {
   // (Overlapping that update with the next block's panel chain on a second stream was measured and
   // lost 5 %: the panel kernels then queue behind 50 us trailing-update workgroups.)
   // Row tiles run to nt inclusive: tile row nt is the right-hand side.
-  constexpr int kOuter = 8;
+  constexpr int kOuter = 8;  // 6 and 8 measure the same; 4 and 10+ are slower
   for (int p0 = 0; p0 < nt; p0 += kOuter) {
     const int p1 = p0 + kOuter < nt ? p0 + kOuter : nt;
     for (int p = p0; p < p1; ++p) {
