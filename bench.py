@@ -145,10 +145,17 @@ def main():
             raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
+    # rehearsal on a one-GPU box: every rank on device 0, collectives through gloo (everything but RCCL itself)
+    rehearsal = os.environ.get("HIPBA_BENCH_ONE_DEVICE") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     solver = hipba.Solver(local_rank)
     prob, _, _ = scenes.bal_scale(seed=3000, n_points=args.points)
