@@ -356,3 +356,53 @@ def test_staged_schur_accumulation_matches_oracle(solver, oracle):
     g2 = prob.copy()
     solver.solve(g2, hipba.default_options(max_num_iterations=6))
     assert np.abs(g.poses - g2.poses).max() <= 1e-11
+
+
+def _check_against_oracle(oracle, prob, gpu_prob, summary, loss=None, loss_scale=1.0, max_iter=300):
+    o = to_oracle(oracle, prob)
+    kw = dict(max_num_iterations=max_iter, jacobian_mode=oracle.JAC_ANALYTIC, num_threads=8)
+    if loss is not None:
+        kw.update(loss=loss, loss_scale=loss_scale)
+    so, oits = oracle.solve(o, oracle.default_options(**kw))
+    assert summary["termination_type"] == so["termination_type"]
+    assert abs(summary["final_cost"] - so["final_cost"]) <= RTOL_COST * max(so["final_cost"], 1e-12)
+    assert np.abs(gpu_prob.poses - o.poses).max() <= ATOL_STATE
+    assert np.abs(gpu_prob.points - o.points).max() <= ATOL_STATE
+    assert_logs_match(summary["iterations"], oits)
+
+
+@pytest.mark.parametrize("n_frames", [2, 3, 7, 21, 22, 23, 32, 33])
+def test_window_sizes_across_the_accumulation_modes(solver, oracle, n_frames):
+    """Window sizes on both sides of every switch in the elimination kernels: whole S in LDS (<= 21 variable
+    poses), b only in LDS (<= 32), atomics into HBM with the large-matrix solver (33+)."""
+    prob, _, _ = scenes.small_window(4000 + n_frames, n_frames=n_frames, n_points=600)
+    g = prob.copy()
+    s = solver.solve(g, hipba.reference_production_options())
+    assert s["num_active_poses"] == n_frames - 1
+    _check_against_oracle(oracle, prob, g, s)
+
+
+def test_mixed_batch_of_window_sizes_with_huber_loss(solver, oracle):
+    wins = [scenes.small_window(4100 + i, n_frames=nf, n_points=300)[0] for i, nf in enumerate([2, 5, 9, 14, 20, 26, 32])]
+    batch = [w.copy() for w in wins]
+    opts = hipba.default_options(max_num_iterations=50, loss=hipba.LOSS_HUBER, loss_scale=1.5)
+    res = solver.solve_batched(batch, opts, log=True)
+    for w, g, s in zip(wins, batch, res):
+        _check_against_oracle(oracle, w, g, s, loss=oracle.LOSS_HUBER, loss_scale=1.5, max_iter=50)
+
+
+@pytest.mark.parametrize("n_frames", [30, 40])
+def test_long_tracks_pair_lists_beyond_the_lds_stage(solver, oracle, n_frames):
+    """Every landmark seen by every keyframe: a 256-observation block then carries more than 4096 pairs, which
+    takes the elimination kernel's path that reads its pair and run lists from HBM instead of LDS."""
+    rng = np.random.default_rng(77 + n_frames)
+    gt_p, gt_q, poses, points, op, oq, uv = scenes._window(rng, n_frames, 200, n_frames, n_frames, depth_lo=30.0,
+                                                            depth_hi=60.0)
+    deg = np.bincount(oq, minlength=200)
+    assert deg.max() == n_frames and (deg * (deg + 1) // 2).max() * (256 // n_frames) > 4096 or n_frames < 40
+    pc, qc = scenes._production_constants(n_frames, 200, op, oq)
+    qc[:] = 0  # keep the landmarks variable so that every pair is formed
+    prob = hipba.Problem(poses, points, op, oq, uv, scenes.KITTI_K, hipba.CAMERA_Z_FORWARD, pc, qc)
+    g = prob.copy()
+    s = solver.solve(g, hipba.default_options(max_num_iterations=30))
+    _check_against_oracle(oracle, prob, g, s, max_iter=30)
