@@ -1338,25 +1338,45 @@ __global__ __launch_bounds__(kBlock) void k_residual_jacobian(CameraK K, LmParam
                                                               const double* __restrict__ obs_uv, double* res,
                                                               double* jac_pose, double* jac_point, double* cost_part) {
   __shared__ double red[4];
-  const long long o = (long long)blockIdx.x * kBlock + threadIdx.x;
+  // the 12 + 6 Jacobian doubles of a lane are turned around in LDS (odd pitches: no bank conflicts) so that
+  // the block's 24 KB + 12 KB leave as contiguous 16-byte-per-lane streaming stores
+  __shared__ __attribute__((aligned(16))) double sJ[kBlock * 13];
+  const int t = threadIdx.x;
+  const long long o0 = (long long)blockIdx.x * kBlock, o = o0 + t;
+  const int nvalid = (int)(n_obs - o0 < kBlock ? n_obs - o0 : kBlock);
   double c[1] = {0.0};
+  double r[2] = {0.0, 0.0}, Jc[12], Jp[6];
   if (o < n_obs) {
     const double2 uv = reinterpret_cast<const double2*>(obs_uv)[o];
-    double r[2], Jc[12], Jp[6];
     LmParams l2 = lm;
     if (!apply_loss) l2.loss = HIPBA_LOSS_NONE;
     c[0] = eval_obs<true>(K, l2, poses + 7ll * obs_pose[o], points + 3ll * obs_point[o], uv.x, uv.y, nullptr, nullptr,
                           r, Jc, Jp);
     if (res) reinterpret_cast<double2*>(res)[o] = make_double2(r[0], r[1]);
-    if (jac_pose) {
-      double2* jp = reinterpret_cast<double2*>(jac_pose + 12 * o);
+  }
+  if (jac_pose) {
+    if (o < n_obs) {
 #pragma unroll
-      for (int i = 0; i < 6; ++i) jp[i] = make_double2(Jc[2 * i], Jc[2 * i + 1]);
+      for (int i = 0; i < 12; ++i) sJ[13 * t + i] = Jc[i];
     }
-    if (jac_point) {
-      double2* jq = reinterpret_cast<double2*>(jac_point + 6 * o);
+    __syncthreads();
+    double* dst = jac_pose + 12 * o0;
+    for (int idx = t; idx < 12 * nvalid; idx += kBlock) {
+      const int l = idx / 12;
+      dst[idx] = sJ[13 * l + (idx - 12 * l)];
+    }
+    __syncthreads();
+  }
+  if (jac_point) {
+    if (o < n_obs) {
 #pragma unroll
-      for (int i = 0; i < 3; ++i) jq[i] = make_double2(Jp[2 * i], Jp[2 * i + 1]);
+      for (int i = 0; i < 6; ++i) sJ[7 * t + i] = Jp[i];
+    }
+    __syncthreads();
+    double* dst = jac_point + 6 * o0;
+    for (int idx = t; idx < 6 * nvalid; idx += kBlock) {
+      const int l = idx / 6;
+      dst[idx] = sJ[7 * l + (idx - 6 * l)];
     }
   }
   block_sum<1>(c, red);

@@ -263,9 +263,9 @@ def test_sharded_solve_equals_unsharded(oracle):
     """Two ranks on one GPU (threads, each with its own handle and stream); the all-reduce callback
     stages through host memory.  Exercises the reduce/decide kernel modes and the owner rule without RCCL."""
     import ctypes as C
-    import torch
-    torch.cuda.init()  # the two rank threads would otherwise race through torch's lazy device initialisation
-    torch.cuda.synchronize()
+    hip = C.CDLL("libamdhip64.so")  # the callback stages through host memory with plain HIP copies
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
     prob, _, _ = scenes.bal_scale(seed=5, grid=(6, 7), n_points=6000, depth_lo=5.0, depth_hi=25.0)
     opts = lambda: hipba.default_options(max_num_iterations=6)
     ref = prob.copy()
@@ -276,17 +276,16 @@ def test_sharded_solve_equals_unsharded(oracle):
     results = [None] * world
 
     def make_cb(rank):
-        from stereo_visual_odometry_amd.sharded import tensor_from_pointer
         def cb(ctx, buf, count, op, stream):
             try:
-                torch.cuda.synchronize()
-                t = tensor_from_pointer(buf, count, "cuda:0")
-                slots[rank] = t.cpu()
-                barrier.wait()
-                tot = torch.stack(slots).sum(0) if op == hipba.REDUCE_SUM else torch.stack(slots).max(0).values
-                barrier.wait()
-                t.copy_(tot.cuda())
-                torch.cuda.synchronize()
+                assert hip.hipStreamSynchronize(stream) == 0
+                mine = np.empty(count, dtype=np.float64)
+                assert hip.hipMemcpy(mine.ctypes.data, buf, 8 * count, 2) == 0   # device to host
+                slots[rank] = mine
+                barrier.wait(timeout=60)
+                tot = np.sum(slots, axis=0) if op == hipba.REDUCE_SUM else np.max(slots, axis=0)
+                barrier.wait(timeout=60)
+                assert hip.hipMemcpy(buf, tot.ctypes.data, 8 * count, 1) == 0    # host to device
                 return 0
             except Exception as e:  # pragma: no cover
                 print("callback failed", repr(e))
