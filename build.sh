@@ -24,3 +24,5 @@ g++ -O2 -std=c++17 -Wall -Iinclude -I$SRC/host -o $OUT/ba_replay $SRC/host/ba_re
 echo "built $OUT/ba_replay"
 g++ -O2 -std=c++17 -Wall -pthread -Iinclude -I$SRC/host -o $OUT/ba_stage_demo $SRC/host/ba_stage_demo.cpp -L$OUT -lhipba -Wl,-rpath,'$ORIGIN'
 echo "built $OUT/ba_stage_demo"
+g++ -O2 -std=c++17 -Wall -Iinclude -I$SRC/host -o $OUT/kitti_info $SRC/host/kitti_info_cli.cpp
+echo "built $OUT/kitti_info"
