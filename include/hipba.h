@@ -138,6 +138,9 @@ typedef struct hipba_summary {
   hipba_iteration* iteration_log;
   int32_t iteration_log_capacity;
   int32_t reserved2;
+  /* bytes this call moved over the host link (for a batched call: the whole call, in every summary) */
+  int64_t bytes_host_to_device;
+  int64_t bytes_device_to_host;
 } hipba_summary;
 
 typedef struct hipba_handle_s* hipba_handle;          /* one per calling thread and GPU */

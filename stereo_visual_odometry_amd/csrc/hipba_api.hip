@@ -84,6 +84,8 @@ struct hipba_device_problem_s {
   int* d_count = nullptr;
   int max_ncam = 0;
   int max_pm_blocks = 0;      // most PM blocks in one window
+  long long upload_bytes = 0; // host-to-device bytes of the upload
+  long long d2h_bytes = 0;    // device-to-host bytes since the last solve started
   int n_blocks = 0;
   long long S_doubles = 0;
   BigWork big;
@@ -584,6 +586,7 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   up.add(&d_runs, std::max<size_t>(runs.size(), 1));
   if (staged) { up.add(&d_pair_obs, pair_obs.size()); up.add(&d_dest_start, dest_start.size()); }
   const size_t upload_bytes = up.total;
+  R->upload_bytes = (long long)upload_bytes;
   ArenaPlan work = up;  // continues after the uploaded region
   work.items.clear();
   const size_t ns = std::max(n_slots, 1), npp = std::max(n_pm_points, 1);
@@ -793,12 +796,14 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
   // summaries
   std::vector<WinState> ws(P.n_windows);
   HIPBA_HIP(hipMemcpy(ws.data(), P.ws, sizeof(WinState) * P.n_windows, hipMemcpyDeviceToHost));
+  R->d2h_bytes = (long long)sizeof(WinState) * P.n_windows;
   std::vector<hipba_iteration> log;
   bool want_log = o.minimizer_progress_to_stdout != 0;
   for (int w = 0; w < P.n_windows && !want_log; ++w) want_log = summaries[w].iteration_log != nullptr;
   if (want_log && P.log_cap > 0) {
     log.resize((size_t)P.log_cap * P.n_windows);
     HIPBA_HIP(hipMemcpy(log.data(), P.log, sizeof(hipba_iteration) * log.size(), hipMemcpyDeviceToHost));
+    R->d2h_bytes += (long long)(sizeof(hipba_iteration) * log.size());
   }
   for (int w = 0; w < P.n_windows; ++w) {
     hipba_summary& sm = summaries[w];
@@ -820,6 +825,8 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
     sm.num_active_observations = R->meta[w].n_act_obs;
     sm.time_solve_s = t1 - t0;
     sm.linear_solver_used = solver;
+    sm.bytes_host_to_device = 0;
+    sm.bytes_device_to_host = R->d2h_bytes + 4ll * sm.num_linear_solves;  // + the 4-byte activity poll of every pass
     if (user_log && !log.empty()) {
       const int n = std::min(std::min(sm.num_iterations, user_cap), P.log_cap);
       memcpy(user_log, log.data() + (size_t)w * P.log_cap, sizeof(hipba_iteration) * n);
@@ -841,12 +848,15 @@ int download_all(hipba_handle_s* h, hipba_device_problem_s* R, hipba_problem* pr
   const DevP& P = R->P;
   std::vector<WinState> ws(P.n_windows);
   HIPBA_HIP(hipMemcpy(ws.data(), P.ws, sizeof(WinState) * P.n_windows, hipMemcpyDeviceToHost));
+  R->d2h_bytes += (long long)sizeof(WinState) * P.n_windows;
   std::vector<double> poses[2], points[2];
   for (int k = 0; k < 2; ++k) {
+    if (P.n_windows == 1 && k != ws[0].sel) continue;  // one window: only the buffer that holds x
     poses[k].resize(std::max<size_t>(7 * (size_t)P.n_poses, 7));
     points[k].resize(std::max<size_t>(3 * (size_t)P.n_pm_points, 3));
     if (P.n_poses) HIPBA_HIP(hipMemcpyAsync(poses[k].data(), P.poses[k], sizeof(double) * 7 * P.n_poses, hipMemcpyDeviceToHost, h->stream));
     if (P.n_pm_points) HIPBA_HIP(hipMemcpyAsync(points[k].data(), P.points[k], sizeof(double) * 3 * P.n_pm_points, hipMemcpyDeviceToHost, h->stream));
+    R->d2h_bytes += 8ll * (7ll * P.n_poses + 3ll * P.n_pm_points);
   }
   HIPBA_HIP(hipStreamSynchronize(h->stream));
   for (int w = 0; w < P.n_windows; ++w) {
@@ -956,12 +966,15 @@ int hipba_solve_batched(hipba_handle h, int32_t n_windows, hipba_problem* proble
   const double t1 = now_s();
   rc = run_lm(h, R, o, nullptr, summaries);
   if (!rc) rc = download_all(h, R, problems, summaries);
+  const long long upload_bytes = R->upload_bytes, d2h_bytes = R->d2h_bytes + 4ll * (n_windows > 0 ? summaries[0].num_linear_solves : 0);
   free_resident(R);
   const double t2 = now_s();
   if (!rc) {
     for (int w = 0; w < n_windows; ++w) {
       summaries[w].time_setup_s = t1 - t0;
       summaries[w].time_total_s = t2 - t0;
+      summaries[w].bytes_host_to_device = upload_bytes;
+      summaries[w].bytes_device_to_host = d2h_bytes;
     }
   }
   return rc;

@@ -74,6 +74,7 @@ class CSummary(C.Structure):
         ("time_setup_s", C.c_double), ("time_solve_s", C.c_double), ("time_total_s", C.c_double),
         ("linear_solver_used", C.c_int32), ("num_linear_solves", C.c_int32),
         ("iteration_log", C.POINTER(CIteration)), ("iteration_log_capacity", C.c_int32), ("reserved2", C.c_int32),
+        ("bytes_host_to_device", C.c_int64), ("bytes_device_to_host", C.c_int64),
     ]
 
 
