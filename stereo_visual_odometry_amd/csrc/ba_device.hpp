@@ -124,13 +124,16 @@ struct DevP {
   const BlockDesc* blocks;
   const unsigned short* pairs;    // low byte = lane i, high byte = lane j, slot_i <= slot_j
   const RunDesc* runs;            // pair lists cut into runs of one destination (absent in staged mode)
-  // gathered accumulation of the reduced matrix (one large window): Y and W of every observation are kept
-  // in HBM, and every 6x6 block of S sums its products from a list of observation pairs ordered by
-  // destination block (CSR dest_start); null when fp64 atomics are used instead
-  const uint2* pair_obs;          // [n_pairs] (observation i, observation j), indices into the PM section
-  const long long* dest_start;    // [n_dest + 1]
-  double* yw;                     // [36 * n_pm_obs]: Y (18) then W (18) per observation
-  long long n_dest;
+  // gathered accumulation of the reduced matrix (one large window): every 6x6 block of S sums the products of
+  // its observation pairs, listed in destination order; a product is recomputed from the landmark's record
+  // and the two poses, so nothing per observation is kept in HBM.  Null when fp64 atomics are used instead.
+  const uint2* pair_pt;           // [n_pairs] (landmark, (row slot << 16) | column slot)
+  const uint2* pair_obs;          // [n_pairs] (observation i, observation j): where a robust loss reads its weights
+  const long long* chunk_start;   // [n_chunks + 1] pair ranges cut at destination boundaries, one wave each
+  int n_chunks;
+  double* prec;                   // [16 * n_pm_points] landmark record: p (3), scale_p (3), V^-1 (6), 4 unused
+  double* fw;                     // [n_pm_obs] sqrt(rho') of every observation (robust loss only)
+  double* cam_tab;                // [18 * n_act_poses] R^T (9), R^T t (3), scale_c (6) of every variable pose
   const WinDesc* wd;
   WinState* ws;
   // work arrays

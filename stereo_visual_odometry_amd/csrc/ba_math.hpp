@@ -58,13 +58,9 @@ __host__ __device__ __forceinline__ void residual_only(const CameraK& K, const d
   project_residual(K, pc, u, v, r);
 }
 
-// residual + tangent-space Jacobians: Jc 2x6 row-major, Jp 2x3 row-major
-__host__ __device__ __forceinline__ void residual_jacobian(const CameraK& K, const double* pose, const double* p, double u, double v,
-                                                  double* r, double* Jc, double* Jp) {
-  double Rt[9], pc[3];
-  quat_to_Rt(pose, Rt);
-  to_camera(Rt, pose + 4, p, pc);
-  project_residual(K, pc, u, v, r);
+// tangent-space Jacobians from the camera-frame point: Jc 2x6 row-major, Jp 2x3 row-major
+__host__ __device__ __forceinline__ void projection_jacobians(const CameraK& K, const double* Rt, const double* pc, double* Jc,
+                                                     double* Jp) {
   double A[6];
   if (K.model == 0) {
     const double iz = 1.0 / pc[2];
@@ -87,6 +83,16 @@ __host__ __device__ __forceinline__ void residual_jacobian(const CameraK& K, con
     Jp[3 * row + 1] = a0 * Rt[1] + a1 * Rt[4] + a2 * Rt[7];
     Jp[3 * row + 2] = a0 * Rt[2] + a1 * Rt[5] + a2 * Rt[8];
   }
+}
+
+// residual + tangent-space Jacobians
+__host__ __device__ __forceinline__ void residual_jacobian(const CameraK& K, const double* pose, const double* p, double u, double v,
+                                                  double* r, double* Jc, double* Jp) {
+  double Rt[9], pc[3];
+  quat_to_Rt(pose, Rt);
+  to_camera(Rt, pose + 4, p, pc);
+  project_residual(K, pc, u, v, r);
+  projection_jacobians(K, Rt, pc, Jc, Jp);
 }
 
 // ceres::HuberLoss::Evaluate followed by Corrector: returns rho0 and the sqrt(rho1) factor

@@ -388,16 +388,16 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   const int n_blocks = (int)blocks.size();
 
   // ---- gathered accumulation (one large window): observation pairs listed per destination block ---------
-  // fp64 atomics into S run at ~1 TB/s of added bytes; beyond a few million 6x6 products it is faster to
-  // keep Y and W of every observation in HBM and let every block of S gather and sum its own products.
-  std::vector<uint2> pair_obs;
-  std::vector<long long> dest_start;
-  long long n_dest = 0;
-  const bool staged = nw == 1 && max_ncam > 20 && pairs.size() >= (size_t)2000000 && n_pm_obs < 0xffffffffll;
+  // fp64 atomics into S run at ~1 TB/s of added bytes; beyond a few million 6x6 products it is faster to let
+  // every block of S sum its own products, each recomputed from the landmark's record and the two poses.
+  std::vector<uint2> pair_obs, pair_pt;
+  std::vector<long long> chunk_start;
+  const bool staged = nw == 1 && max_ncam > 20 && max_ncam <= 0xffff && pairs.size() >= (size_t)2000000 &&
+                      n_pm_obs < 0xffffffffll;
   if (staged) {
     const int ncam = wd[0].ncam;
-    n_dest = (long long)ncam * (ncam + 1) / 2;
-    dest_start.assign(n_dest + 1, 0);
+    const long long n_dest = (long long)ncam * (ncam + 1) / 2;
+    std::vector<long long> dest_start(n_dest + 1, 0);
     std::vector<long long> dest_of(pairs.size());
     for (const BlockDesc& d : blocks) {
       if (d.kind != 0) continue;
@@ -413,14 +413,26 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
     for (long long i = 0; i < n_dest; ++i) dest_start[i + 1] += dest_start[i];
     std::vector<long long> cur(dest_start.begin(), dest_start.end() - 1);
     pair_obs.resize((size_t)dest_start[n_dest]);
+    pair_pt.resize(pair_obs.size());
     for (const BlockDesc& d : blocks) {
       if (d.kind != 0) continue;
       for (int q = 0; q < d.n_pairs; ++q) {
         const unsigned short pr = pairs[d.pair_begin + q];
-        pair_obs[cur[dest_of[d.pair_begin + q]]++] =
-            make_uint2((unsigned)(d.obs_begin + (pr & 0xff)), (unsigned)(d.obs_begin + (pr >> 8)));
+        const long long oi = d.obs_begin + (pr & 0xff), oj = d.obs_begin + (pr >> 8);
+        const unsigned si = (unsigned)(pose_gslot[obs_pose[oi]] - wd[0].cam_base);
+        const unsigned sj = (unsigned)(pose_gslot[obs_pose[oj]] - wd[0].cam_base);
+        const long long at = cur[dest_of[d.pair_begin + q]]++;
+        pair_obs[at] = make_uint2((unsigned)oi, (unsigned)oj);
+        pair_pt[at] = make_uint2((unsigned)obs_dp[oi], (si << 16) | sj);
       }
     }
+    // one wave per chunk of about kGatherChunk pairs; a chunk holds whole destinations, so every block of S
+    // has exactly one writer
+    const long long kGatherChunk = 1024;
+    chunk_start.push_back(0);
+    for (long long dd = 0; dd < n_dest; ++dd)
+      if (dest_start[dd + 1] - chunk_start.back() >= kGatherChunk) chunk_start.push_back(dest_start[dd + 1]);
+    if (chunk_start.back() != dest_start[n_dest]) chunk_start.push_back(dest_start[n_dest]);
     pairs.assign(8, kPairPad);  // the blocks themselves need no pair lists in this mode
   }
 
@@ -567,7 +579,7 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   long long *d_cm_start, *d_pp_start;
   double *d_cm_uv, *d_obs_uv;
   BlockDesc* d_blocks; unsigned short* d_pairs; WinDesc* d_wd; RunDesc* d_runs;
-  uint2* d_pair_obs = nullptr; long long* d_dest_start = nullptr;
+  uint2 *d_pair_obs = nullptr, *d_pair_pt = nullptr; long long* d_chunk_start = nullptr;
   up.add(&P.poses[0], poses.size());
   up.add(&P.points[0], points.size());
   up.add(&d_pose_window, std::max<size_t>(pose_window.size(), 1));
@@ -584,7 +596,7 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   up.add(&d_pairs, std::max<size_t>(pairs.size(), 1));
   up.add(&d_wd, wd.size());
   up.add(&d_runs, std::max<size_t>(runs.size(), 1));
-  if (staged) { up.add(&d_pair_obs, pair_obs.size()); up.add(&d_dest_start, dest_start.size()); }
+  if (staged) { up.add(&d_pair_obs, pair_obs.size()); up.add(&d_pair_pt, pair_pt.size()); up.add(&d_chunk_start, chunk_start.size()); }
   const size_t upload_bytes = up.total;
   R->upload_bytes = (long long)upload_bytes;
   ArenaPlan work = up;  // continues after the uploaded region
@@ -609,7 +621,7 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   work.add(&P.wsum, (size_t)8 * nw);
   work.add(&P.log, (size_t)std::max(log_cap, 1) * nw);
   work.add(&R->d_count, 4);
-  if (staged) { work.add(&P.yw, 36 * (size_t)n_pm_obs); work.add(&P.vg, 3 * npp); }
+  if (staged) { work.add(&P.prec, 16 * npp); work.add(&P.fw, (size_t)n_pm_obs); work.add(&P.cam_tab, 18 * ns); work.add(&P.vg, 3 * npp); }
   char* big_base_dummy = nullptr;
   size_t big_bytes = 0;
   if (6 * max_ncam > kSmallMaxN) {
@@ -644,8 +656,9 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   P.cm_start = d_cm_start; P.cm_dp = d_cm_dp; P.cm_uv = d_cm_uv;
   P.obs_pose = d_obs_pose; P.obs_dp = d_obs_dp; P.obs_uv = d_obs_uv; P.pp_obs_start = d_pp_start;
   P.blocks = d_blocks; P.pairs = d_pairs; P.wd = d_wd; P.runs = d_runs;
-  P.pair_obs = d_pair_obs; P.dest_start = d_dest_start; P.n_dest = n_dest;
-  if (!staged) { P.yw = nullptr; P.vg = nullptr; }
+  P.pair_obs = d_pair_obs; P.pair_pt = d_pair_pt; P.chunk_start = d_chunk_start;
+  P.n_chunks = staged ? (int)chunk_start.size() - 1 : 0;
+  if (!staged) { P.prec = nullptr; P.fw = nullptr; P.cam_tab = nullptr; P.vg = nullptr; }
 
   char* st = static_cast<char*>(h->staging);
   auto stage = [&](const void* dev_ptr, const void* src, size_t bytes) {
@@ -669,7 +682,8 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   stage(d_runs, runs.data(), runs.size() * sizeof(RunDesc));
   if (staged) {
     stage(d_pair_obs, pair_obs.data(), pair_obs.size() * sizeof(uint2));
-    stage(d_dest_start, dest_start.data(), dest_start.size() * 8);
+    stage(d_pair_pt, pair_pt.data(), pair_pt.size() * sizeof(uint2));
+    stage(d_chunk_start, chunk_start.data(), chunk_start.size() * 8);
   }
   hipStream_t s = h->stream;
   hipError_t e = hipMemcpyAsync(R->arena, h->staging, upload_bytes, hipMemcpyHostToDevice, s);

@@ -74,7 +74,8 @@ __device__ __forceinline__ void atomic_add_f64(double* p, double v) { unsafeAtom
 template <bool WITH_JP>
 __device__ __forceinline__ double eval_obs(const CameraK& K, const LmParams& lm, const double* pose, const double* p,
                                            double u, double v, const double* sc /*6 or null*/,
-                                           const double* sp /*3 or null*/, double* r, double* Jc, double* Jp) {
+                                           const double* sp /*3 or null*/, double* r, double* Jc, double* Jp,
+                                           double* loss_factor = nullptr) {
   double jp_local[6];
   double* jp = WITH_JP ? Jp : jp_local;
   residual_jacobian(K, pose, p, u, v, r, Jc, jp);
@@ -83,6 +84,7 @@ __device__ __forceinline__ double eval_obs(const CameraK& K, const LmParams& lm,
   if (lm.loss == HIPBA_LOSS_HUBER) {
     double f;
     huber_correct(lm.loss_scale, s, &rho0, &f);
+    if (loss_factor) *loss_factor = f;
     r[0] *= f; r[1] *= f;
 #pragma unroll
     for (int i = 0; i < 12; ++i) Jc[i] *= f;
@@ -341,6 +343,18 @@ __global__ void k_init_reduced(DevP P, LmParams lm, int owner) {
   // stash per pose in yc (overwritten by the solver afterwards): [0]=max, [1]=sum of squares
   P.yc[6ll * g + 0] = m;
   P.yc[6ll * g + 1] = s2;
+  if (P.cam_tab) {
+    // what k_schur_gather needs of a pose, once per iteration instead of once per product
+    double* ct = P.cam_tab + 18ll * g;
+    double Rt[9];
+    quat_to_Rt(xx, Rt);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) ct[i] = Rt[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) ct[9 + i] = Rt[3 * i] * xx[4] + Rt[3 * i + 1] * xx[5] + Rt[3 * i + 2] * xx[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) ct[12 + i] = P.scale_c[6ll * g + i];
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -439,8 +453,9 @@ __device__ __forceinline__ void pair_products(const unsigned short* pairs, const
 }
 
 // MODE 0: fp64 atomics straight into S, one workgroup per block.
-// MODE 2 (gathered): Y and W of every observation are written to HBM; k_schur_gather then lets every block
-//   of S sum its own products from a list of observation pairs (no atomics on S, fixed order).
+// MODE 2 (gathered): only V^-1, g_p and V^-1 g_p are formed here and left in the landmark's record;
+//   k_schur_gather then lets every block of S sum its own products from a list of observation pairs,
+//   recomputing each from the record and the two poses (no atomics on S, fixed order).
 // MODE 1 / 3 (windows of at most kSmallMaxN/6 poses): `parts` workgroups per window, each walking every
 //   parts-th block of the window; b is accumulated in LDS and flushed once per workgroup, and so is the
 //   whole packed S when it fits (MODE 1; MODE 3 sends S to HBM with atomics).  A product is shared by two
@@ -450,9 +465,10 @@ __global__ __launch_bounds__(kBlock) void k_point_schur(DevP P, LmParams lm, int
   constexpr bool SMALL = MODE == 1 || MODE == 3;
   constexpr bool LDS_S = MODE == 1;
   extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr int kStage = MODE == 2 ? 9 : kYW;  // gathered mode stages only the phase-1 words
   double* sYW = smem;                         // [kBlock][kYW]: Y (18) then W (18); phase 1 aliases 9 words/lane
-  int* sslot = reinterpret_cast<int*>(smem + kBlock * kYW);  // [kBlock] local slot or -1
-  double* red = smem + kBlock * kYW + kBlock / 2;            // [8]
+  int* sslot = reinterpret_cast<int*>(smem + kBlock * kStage);  // [kBlock] local slot or -1
+  double* red = smem + kBlock * kStage + kBlock / 2;            // [8]
   unsigned short* sPairs = reinterpret_cast<unsigned short*>(red + 8);   // [kLdsPairs] (not in staged mode)
   RunDesc* sRuns = reinterpret_cast<RunDesc*>(sPairs + kLdsPairs);      // [kLdsRuns]
   double* accB = reinterpret_cast<double*>(sRuns + kLdsRuns);           // SMALL: b, then (LDS_S) packed S
@@ -514,8 +530,10 @@ __global__ __launch_bounds__(kBlock) void k_point_schur(DevP P, LmParams lm, int
       const double* pose = P.poses[sel] + 7ll * c;
       const double* p = P.points[sel] + 3ll * pp;
       const double2 uv = reinterpret_cast<const double2*>(P.obs_uv)[o];
+      double lf = 1.0;
       eval_obs<true>(wd.K, lm, pose, p, uv.x, uv.y, g < 0 ? nullptr : P.scale_c + 6ll * g, P.scale_p + 3ll * pp, r,
-                     Jc, Jp);
+                     Jc, Jp, &lf);
+      if (MODE == 2 && lm.loss != HIPBA_LOSS_NONE) P.fw[o] = lf;
       double* cw = sYW + 9 * t;
       cw[0] = Jp[0] * Jp[0] + Jp[3] * Jp[3];
       cw[1] = Jp[0] * Jp[1] + Jp[3] * Jp[4];
@@ -564,8 +582,16 @@ __global__ __launch_bounds__(kBlock) void k_point_schur(DevP P, LmParams lm, int
             P.vg[3ll * pp + i] = sp * (Vi[r0] * gpv[0] + Vi[r1] * gpv[1] + Vi[r2] * gpv[2]);
           }
         }
+        if (MODE == 2) {
+          double* rec = P.prec + 16ll * pp;
+          const double* p = P.points[sel] + 3ll * pp;
+#pragma unroll
+          for (int i = 0; i < 3; ++i) { rec[i] = p[i]; rec[3 + i] = P.scale_p[3ll * pp + i]; }
+#pragma unroll
+          for (int i = 0; i < 6; ++i) rec[6 + i] = Vi[i];
+        }
       }
-      if (slot >= 0) {
+      if (MODE != 2 && slot >= 0) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
 #pragma unroll
@@ -597,7 +623,7 @@ __global__ __launch_bounds__(kBlock) void k_point_schur(DevP P, LmParams lm, int
         reinterpret_cast<uint4*>(sRuns)[t + m * kBlock] = rv[m];
       }
     }
-    if (live) {
+    if (MODE != 2 && live) {
       sslot[t] = slot;
       if (slot >= 0) {
         double* yw = sYW + kYW * t;
@@ -609,15 +635,7 @@ __global__ __launch_bounds__(kBlock) void k_point_schur(DevP P, LmParams lm, int
     HIPBA_TICK(4);
 
     // phase 3: pair products (staged mode: every product to its own slot; otherwise run by run)
-    if (MODE == 2) {
-      // Y and W of the block's observations go to HBM as they lie in LDS (coalesced); k_schur_gather forms the
-      // products.  Lanes without a variable pose carry no data, and no pair refers to them.
-      double* dst = P.yw + 36ll * d.obs_begin;
-      for (int idx = t; idx < 36 * d.n_obs; idx += kBlock) {
-        const int i = idx / 36;
-        dst[idx] = sYW[i * kYW + (idx - 36 * i)];
-      }
-    } else {
+    if (MODE != 2) {
       double* Sbase = LDS_S ? accS : P.S + wd.S_off;
       if (lists_in_lds) pair_products<!LDS_S>(sPairs, sRuns, d.n_runs, sYW, Sbase, t);
       else pair_products<!LDS_S>(P.pairs + d.pair_begin, P.runs + d.run_begin, d.n_runs, sYW, Sbase, t);
@@ -657,53 +675,143 @@ __global__ __launch_bounds__(kBlock) void k_point_schur(DevP P, LmParams lm, int
   HIPBA_TICK(7);
 }
 
-// gathered mode: S(block d) -= sum over its observation pairs of Y_i W_j^T.  One wave per destination block,
-// sixteen pairs per batch: lanes 0-15 fetch the batch's pair records, the wave then loads the 16 x 36 operand
-// doubles (Y_i then W_j of each pair: 144-byte runs, nine loads per lane) and parks them in its LDS slice; lanes
-// 0-35 (lane e = 6 a + c owns entry (a, c)) read their row of Y and column of W back and accumulate.
-// Consecutive destinations share their row camera, so the Y rows mostly come from L2; the W rows are the HBM
-// traffic (144 B per pair).  Fixed summation order: S is reproducible run to run.
-constexpr int kGatherBatch = 16;
-__global__ __launch_bounds__(kBlock) void k_schur_gather(DevP P, long long n_dest) {
-  __shared__ double sOp[kBlock / 64][kGatherBatch * 36];
+// gathered mode: S(block d) -= sum over its observation pairs of Y_i W_j^T.  A wave owns a chunk of the
+// destination-ordered pair list (whole destinations) and takes it 64 pairs at a time, one pair per lane:
+//   the 64 landmark records (one aligned 128-byte line each) are loaded line by line, eight lanes to a line, and
+//   handed to their lanes through LDS; a lane rebuilds the two observations' Jacobians from the record and the
+//   two rows of the camera table, and forms the product in the factored form
+//     Y_i W_j^T = Jc_i^T [ (Jp_i V^-1 Jp_j^T) Jc_j ]            (2x2 core, then 2x6, then 6x6);
+//   the 64 products go to LDS transposed, and lanes 0-35 (lane e = 6 r + c owns entry (r, c)) sum them
+//   destination by destination in list order.
+// HBM traffic per product: 8 bytes of list and one 128-byte record (the records of a million landmarks are
+// 128 MB and largely stay in the last-level cache); nothing per observation.  Off-diagonal blocks were zeroed
+// and have this one writer: plain stores; diagonal blocks already hold U + D^2: one atomic per entry.
+// Fixed summation order: S is reproducible run to run.
+constexpr int kGatherRow = 65;                // LDS doubles per row of 64 products (odd: rows on different banks)
+constexpr int kGatherRec = 17;                // LDS doubles per staged landmark record
+constexpr int kGatherLds = 36 * kGatherRow;   // doubles per wave (the records, 64 x 17, use the same words first)
+
+#define HIPBA_WAVE_SYNC()                                  \
+  do {                                                     \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+    __builtin_amdgcn_wave_barrier();                       \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+  } while (0)
+
+// scaled Jacobians of one observation from the camera table row (R^T, R^T t, column scales) and the landmark
+__device__ __forceinline__ void gather_side(const CameraK& K, const double* __restrict__ cam, const double* p,
+                                            const double* sp, double* Jc, double* Jp) {
+  double Rt[9], pc[3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Rt[i] = cam[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) pc[i] = Rt[3 * i] * p[0] + Rt[3 * i + 1] * p[1] + Rt[3 * i + 2] * p[2] - cam[9 + i];
+  projection_jacobians(K, Rt, pc, Jc, Jp);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { const double s = cam[12 + i]; Jc[i] *= s; Jc[6 + i] *= s; }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { Jp[i] *= sp[i]; Jp[3 + i] *= sp[i]; }
+}
+
+__global__ __launch_bounds__(kBlock) void k_schur_gather(DevP P, LmParams lm) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
   if (!P.ws[0].active) return;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int e = lane < 36 ? lane : 0, a = e / 6, c = e - 6 * a;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int chunk = blockIdx.x * (kBlock / 64) + wave;
+  if (chunk >= P.n_chunks) return;  // whole waves leave; nothing below synchronises across waves
+  double* sT = smem + wave * kGatherLds;
+  const CameraK K = P.wd[0].K;
+  const int ncam = P.wd[0].ncam;
+  const double* cam_tab = P.cam_tab + 18ll * P.wd[0].cam_base;
   double* S = P.S + P.wd[0].S_off;
-  const double* yw = P.yw;
-  double* op = sOp[wave];
-  for (long long d = (long long)blockIdx.x * (kBlock / 64) + wave; d < n_dest; d += (long long)gridDim.x * (kBlock / 64)) {
-    const long long s0 = P.dest_start[d], s1 = P.dest_start[d + 1];
-    if (s1 == s0) continue;
-    double acc = 0.0;
-    for (long long s = s0; s < s1; s += kGatherBatch) {
-      const int nb = (int)(s1 - s < kGatherBatch ? s1 - s : kGatherBatch);
-      uint2 pr = make_uint2(0u, 0u);
-      if (lane < nb) pr = P.pair_obs[s + lane];
-      double v[9];
+  const bool robust = lm.loss != HIPBA_LOSS_NONE;
+  const int e = lane < 36 ? lane : 0;
+  const long long q0 = P.chunk_start[chunk], q1 = P.chunk_start[chunk + 1];
+  int cur = -1, cur_diag = 0;  // destination being summed by lanes 0-35 (wave-uniform)
+  double acc = 0.0;
+  auto flush = [&]() {
+    if (cur >= 0 && lane < 36) {
+      double* dst = S + 36ll * cur + e;
+      if (cur_diag) atomic_add_f64(dst, -acc);
+      else *dst = -acc;
+    }
+  };
+  for (long long q = q0; q < q1; q += 64) {
+    const int nb = (int)(q1 - q < 64 ? q1 - q : 64);
+    const bool live = lane < nb;
+    const uint2 pe = P.pair_pt[q + (live ? lane : 0)];
+    double2 rv[8];
 #pragma unroll
-      for (int m = 0; m < 9; ++m) {
-        const int q = lane + 64 * m;       // element of the batch: pair u, word k of [Y_i | W_j]
-        const int u = q / 36, k = q - 36 * u;
-        const unsigned oi = __shfl(pr.x, u), oj = __shfl(pr.y, u);
-        v[m] = u < nb ? yw[36ll * (k < 18 ? oi : oj) + k] : 0.0;
-      }
-      __builtin_amdgcn_wave_barrier();     // the previous batch's reads are done (same wave, program order)
+    for (int m = 0; m < 8; ++m) {
+      const unsigned ppu = __shfl(pe.x, 8 * m + (lane >> 3));
+      rv[m] = reinterpret_cast<const double2*>(P.prec + 16ll * ppu)[lane & 7];
+    }
+    double wgt = 1.0;
+    if (robust) {
+      const uint2 po = P.pair_obs[q + (live ? lane : 0)];
+      wgt = P.fw[po.x] * P.fw[po.y];
+      wgt *= wgt;
+    }
+    const int a = (int)(pe.y >> 16), b = (int)(pe.y & 0xffffu);
+    HIPBA_WAVE_SYNC();  // the previous batch's sums have been read
 #pragma unroll
-      for (int m = 0; m < 9; ++m) op[lane + 64 * m] = v[m];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      if (lane < 36) {
-        for (int u = 0; u < nb; ++u) {
-          const double* yp = op + 36 * u + 3 * a;
-          const double* wp = op + 36 * u + 18 + 3 * c;
-          acc += yp[0] * wp[0] + yp[1] * wp[1] + yp[2] * wp[2];
+    for (int m = 0; m < 8; ++m) {
+      double* w = sT + (8 * m + (lane >> 3)) * kGatherRec + 2 * (lane & 7);
+      w[0] = rv[m].x; w[1] = rv[m].y;
+    }
+    HIPBA_WAVE_SYNC();
+    double rec[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) rec[k] = sT[lane * kGatherRec + k];
+    HIPBA_WAVE_SYNC();  // records are in registers; the words are free for the products
+    double JcA[12], JpA[6], JcB[12], JpB[6];
+    gather_side(K, cam_tab + 18ll * a, rec, rec + 3, JcA, JpA);
+    gather_side(K, cam_tab + 18ll * b, rec, rec + 3, JcB, JpB);
+    const double* Vi = rec + 6;
+    double M[4];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const double c0 = JpA[3 * k] * Vi[0] + JpA[3 * k + 1] * Vi[1] + JpA[3 * k + 2] * Vi[2];
+      const double c1 = JpA[3 * k] * Vi[1] + JpA[3 * k + 1] * Vi[3] + JpA[3 * k + 2] * Vi[4];
+      const double c2 = JpA[3 * k] * Vi[2] + JpA[3 * k + 1] * Vi[4] + JpA[3 * k + 2] * Vi[5];
+#pragma unroll
+      for (int l = 0; l < 2; ++l) M[2 * k + l] = (c0 * JpB[3 * l] + c1 * JpB[3 * l + 1] + c2 * JpB[3 * l + 2]) * wgt;
+    }
+    double T[12];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) T[6 * k + c] = M[2 * k] * JcB[c] + M[2 * k + 1] * JcB[6 + c];
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) sT[(6 * r + c) * kGatherRow + lane] = JcA[r] * T[c] + JcA[6 + r] * T[6 + c];
+    }
+    const int dest = live ? (int)tri_index(a, b, ncam) : -1;
+    const int diag = a == b ? 1 : 0;
+    HIPBA_WAVE_SYNC();
+    for (int u0 = 0; u0 < nb; u0 += 8) {
+      double v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = sT[e * kGatherRow + u0 + k];  // columns past nb: stale words, never added
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (u0 + k < nb) {
+          const int du = __builtin_amdgcn_readlane(dest, u0 + k);
+          if (du != cur) {
+            flush();
+            cur = du;
+            cur_diag = __builtin_amdgcn_readlane(diag, u0 + k);
+            acc = 0.0;
+          }
+          acc += v[k];
         }
       }
     }
-    if (lane < 36) S[36 * d + e] -= acc;
   }
+  flush();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1409,7 +1517,7 @@ __global__ void k_count_active(DevP P, int* out) {
 // LDS of k_point_schur: Y/W staging, slots, reduction words; outside staged mode the block's pair and run
 // lists; the small-window modes add b and, up to kLdsSMaxCam poses, the packed S
 size_t schur_lds_bytes(int small_ncam, bool staged) {
-  size_t base = (size_t)kBlock * kYW * 8 + (size_t)kBlock * 4 + 8 * 8;
+  size_t base = (size_t)kBlock * (staged ? 9 : kYW) * 8 + (size_t)kBlock * 4 + 8 * 8;
   if (!staged) base += (size_t)kLdsPairs * 2 + (size_t)kLdsRuns * sizeof(RunDesc);
   if (small_ncam > 0) {
     base += (size_t)kSmallMaxN * 8;
@@ -1465,12 +1573,17 @@ hipError_t launch_point_schur(const DevP& P, const LmParams& lm, int small_ncam,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  if (P.yw) {
+  if (P.prec) {
     hipLaunchKernelGGL(k_point_schur<2>, dim3(P.n_blk_pm), dim3(kBlock), schur_lds_bytes(0, true), s, P, lm, 1);
-    const long long n_dest = P.n_dest;
-    const long long want = (n_dest + kBlock / 64 - 1) / (kBlock / 64);
-    const unsigned grid = (unsigned)(want < 8192 ? want : 8192);
-    hipLaunchKernelGGL(k_schur_gather, dim3(grid), dim3(kBlock), 0, s, P, n_dest);
+    static bool gather_attr_done = false;
+    const size_t gather_lds = (size_t)(kBlock / 64) * kGatherLds * 8;
+    if (!gather_attr_done) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_gather),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)gather_lds);
+      gather_attr_done = true;
+    }
+    const unsigned grid = (unsigned)((P.n_chunks + kBlock / 64 - 1) / (kBlock / 64));
+    if (grid) hipLaunchKernelGGL(k_schur_gather, dim3(grid), dim3(kBlock), gather_lds, s, P, lm);
     hipLaunchKernelGGL(k_camera_rhs, dim3(P.n_act_poses), dim3(kBlock), 0, s, P, lm);
   } else if (small_ncam > 0) {
     if (parts < 1) parts = 1;

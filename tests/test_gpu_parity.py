@@ -345,20 +345,27 @@ def test_cpp_optimizer_adapter_through_ba_test_cli(golden):
     assert abs(final - want) <= 1e-6 * want
 
 
-def test_staged_schur_accumulation_matches_oracle(solver, oracle):
-    # >= 2M 6x6 products switch the reduced-matrix accumulation from atomics to the per-block gather
+@pytest.mark.parametrize("loss", [None, "huber"])
+def test_staged_schur_accumulation_matches_oracle(solver, oracle, loss):
+    # >= 2M 6x6 products switch the reduced-matrix accumulation from atomics to the per-block gather, which
+    # recomputes every product from the landmark's record and the two poses (a robust loss adds per-observation
+    # weights read through the observation pair list)
     prob, _, _ = scenes.bal_scale(seed=21, grid=(10, 10), n_points=60000, depth_lo=5.0, depth_hi=30.0)
+    kw, okw = {}, {}
+    if loss == "huber":
+        kw = dict(loss=hipba.LOSS_HUBER, loss_scale=0.6)       # pixel noise 0.5: a good share of outliers
+        okw = dict(loss=oracle.LOSS_HUBER, loss_scale=0.6)
     g = prob.copy()
-    s = solver.solve(g, hipba.default_options(max_num_iterations=6))
+    s = solver.solve(g, hipba.default_options(max_num_iterations=6, **kw))
     o = to_oracle(oracle, prob)
-    so, oits = oracle.solve(o, oracle.default_options(max_num_iterations=6, jacobian_mode=oracle.JAC_ANALYTIC, num_threads=8))
+    so, oits = oracle.solve(o, oracle.default_options(max_num_iterations=6, jacobian_mode=oracle.JAC_ANALYTIC, num_threads=8, **okw))
     assert s["termination_type"] == so["termination_type"]
     assert abs(s["final_cost"] - so["final_cost"]) <= RTOL_COST * so["final_cost"]
     assert np.abs(g.poses - o.poses).max() <= ATOL_STATE and np.abs(g.points - o.points).max() <= ATOL_STATE
     assert_logs_match(s["iterations"], oits)
-    # S is summed in a fixed order on this path; only the right-hand side still uses atomics
+    # S is summed in a fixed order on this path
     g2 = prob.copy()
-    solver.solve(g2, hipba.default_options(max_num_iterations=6))
+    solver.solve(g2, hipba.default_options(max_num_iterations=6, **kw))
     assert np.abs(g.poses - g2.poses).max() <= 1e-11
 
 
