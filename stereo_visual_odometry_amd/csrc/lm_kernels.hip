@@ -589,6 +589,8 @@ __global__ __launch_bounds__(kBlock) void k_point_schur(DevP P, LmParams lm, int
           for (int i = 0; i < 3; ++i) { rec[i] = p[i]; rec[3 + i] = P.scale_p[3ll * pp + i]; }
 #pragma unroll
           for (int i = 0; i < 6; ++i) rec[6 + i] = Vi[i];
+#pragma unroll
+          for (int i = 12; i < 16; ++i) rec[i] = 0.0;  // the whole line is staged through LDS by the gather: keep it finite
         }
       }
       if (MODE != 2 && slot >= 0) {
@@ -689,7 +691,7 @@ __global__ __launch_bounds__(kBlock) void k_point_schur(DevP P, LmParams lm, int
 // Fixed summation order: S is reproducible run to run.
 constexpr int kGatherRow = 65;                // LDS doubles per row of 64 products (odd: rows on different banks)
 constexpr int kGatherRec = 17;                // LDS doubles per staged landmark record
-constexpr int kGatherLds = 36 * kGatherRow;   // doubles per wave (the records, 64 x 17, use the same words first)
+constexpr int kGatherLds = 36 * kGatherRow + 16;  // doubles per wave (the records, 64 x 17, use the same words first)
 
 #define HIPBA_WAVE_SYNC()                                  \
   do {                                                     \
@@ -699,7 +701,7 @@ constexpr int kGatherLds = 36 * kGatherRow;   // doubles per wave (the records, 
   } while (0)
 
 // scaled Jacobians of one observation from the camera table row (R^T, R^T t, column scales) and the landmark
-__device__ __forceinline__ void gather_side(const CameraK& K, const double* __restrict__ cam, const double* p,
+__device__ __forceinline__ void gather_side(const CameraK& K, const double* cam, const double* p,
                                             const double* sp, double* Jc, double* Jp) {
   double Rt[9], pc[3];
 #pragma unroll
@@ -728,6 +730,9 @@ __global__ __launch_bounds__(kBlock) void k_schur_gather(DevP P, LmParams lm) {
   const bool robust = lm.loss != HIPBA_LOSS_NONE;
   const int e = lane < 36 ? lane : 0;
   const long long q0 = P.chunk_start[chunk], q1 = P.chunk_start[chunk + 1];
+  // the pad column of every row and the words after the last row are read (and multiplied by zero) by the sums
+  if (lane < 36) sT[lane * kGatherRow + 64] = 0.0;
+  if (lane < 16) sT[36 * kGatherRow + lane] = 0.0;
   int cur = -1, cur_diag = 0;  // destination being summed by lanes 0-35 (wave-uniform)
   double acc = 0.0;
   auto flush = [&]() {
@@ -737,15 +742,36 @@ __global__ __launch_bounds__(kBlock) void k_schur_gather(DevP P, LmParams lm) {
       else *dst = -acc;
     }
   };
+  // software pipeline: the list entries run two batches ahead of the arithmetic and the landmark records one,
+  // so a batch's HBM latency is covered by the previous batch's products
+  auto load_entry = [&](long long q) {
+    const long long at = q + lane;
+    return P.pair_pt[at < q1 ? at : q0];
+  };
+  auto load_records = [&](const uint2& ent, double2* rv) {
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const unsigned ppu = __shfl(ent.x, 8 * m + (lane >> 3));
+      rv[m] = reinterpret_cast<const double2*>(P.prec + 16ll * ppu)[lane & 7];
+    }
+  };
+  uint2 pe = load_entry(q0), pe_next = load_entry(q0 + 64);
+  double2 rv[8];
+  load_records(pe, rv);
   for (long long q = q0; q < q1; q += 64) {
     const int nb = (int)(q1 - q < 64 ? q1 - q : 64);
     const bool live = lane < nb;
-    const uint2 pe = P.pair_pt[q + (live ? lane : 0)];
-    double2 rv[8];
+    // this batch's camera rows first (loads return in order), then the prefetches
+    const int a = (int)(pe.y >> 16), b = (int)(pe.y & 0xffffu);
+    double camA[18], camB[18];
+    {
+      const double2* ca = reinterpret_cast<const double2*>(cam_tab + 18ll * a);
+      const double2* cb = reinterpret_cast<const double2*>(cam_tab + 18ll * b);
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      const unsigned ppu = __shfl(pe.x, 8 * m + (lane >> 3));
-      rv[m] = reinterpret_cast<const double2*>(P.prec + 16ll * ppu)[lane & 7];
+      for (int i = 0; i < 9; ++i) {
+        const double2 x = ca[i], y = cb[i];
+        camA[2 * i] = x.x; camA[2 * i + 1] = x.y; camB[2 * i] = y.x; camB[2 * i + 1] = y.y;
+      }
     }
     double wgt = 1.0;
     if (robust) {
@@ -753,7 +779,9 @@ __global__ __launch_bounds__(kBlock) void k_schur_gather(DevP P, LmParams lm) {
       wgt = P.fw[po.x] * P.fw[po.y];
       wgt *= wgt;
     }
-    const int a = (int)(pe.y >> 16), b = (int)(pe.y & 0xffffu);
+    const uint2 pe_next2 = load_entry(q + 128);
+    double2 rv_next[8];
+    load_records(pe_next, rv_next);
     HIPBA_WAVE_SYNC();  // the previous batch's sums have been read
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
@@ -766,8 +794,8 @@ __global__ __launch_bounds__(kBlock) void k_schur_gather(DevP P, LmParams lm) {
     for (int k = 0; k < 12; ++k) rec[k] = sT[lane * kGatherRec + k];
     HIPBA_WAVE_SYNC();  // records are in registers; the words are free for the products
     double JcA[12], JpA[6], JcB[12], JpB[6];
-    gather_side(K, cam_tab + 18ll * a, rec, rec + 3, JcA, JpA);
-    gather_side(K, cam_tab + 18ll * b, rec, rec + 3, JcB, JpB);
+    gather_side(K, camA, rec, rec + 3, JcA, JpA);
+    gather_side(K, camB, rec, rec + 3, JcB, JpB);
     const double* Vi = rec + 6;
     double M[4];
 #pragma unroll
@@ -792,24 +820,49 @@ __global__ __launch_bounds__(kBlock) void k_schur_gather(DevP P, LmParams lm) {
     const int dest = live ? (int)tri_index(a, b, ncam) : -1;
     const int diag = a == b ? 1 : 0;
     HIPBA_WAVE_SYNC();
-    for (int u0 = 0; u0 < nb; u0 += 8) {
-      double v[8];
+    // the batch's runs of one destination, from a ballot of the run heads.  Lanes 0-35 sum a run in list order,
+    // sixteen columns per step with the next run's first sixteen already on their way from LDS; columns
+    // past a run's end are read and multiplied by zero (every word read is a finite product or a zeroed pad)
+    const int prev_dest = __shfl_up(dest, 1);
+    unsigned long long heads = __ballot(live && lane != 0 && dest != prev_dest);
+    const double* row = sT + e * kGatherRow;
+    double v[16], vn[16];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] = sT[e * kGatherRow + u0 + k];  // columns past nb: stale words, never added
+    for (int k = 0; k < 16; ++k) { v[k] = row[k]; vn[k] = 0.0; }
+    int u0 = 0;
+    for (;;) {
+      const int u1 = heads ? __builtin_ctzll(heads) : nb;
+      heads &= heads - 1;
+      if (u1 < nb) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        if (u0 + k < nb) {
-          const int du = __builtin_amdgcn_readlane(dest, u0 + k);
-          if (du != cur) {
-            flush();
-            cur = du;
-            cur_diag = __builtin_amdgcn_readlane(diag, u0 + k);
-            acc = 0.0;
-          }
-          acc += v[k];
-        }
+        for (int k = 0; k < 16; ++k) vn[k] = row[u1 + k];
       }
+      const int du = __builtin_amdgcn_readlane(dest, u0);
+      if (du != cur) {
+        flush();
+        cur = du;
+        cur_diag = __builtin_amdgcn_readlane(diag, u0);
+        acc = 0.0;
+      }
+      const int len = u1 - u0;
+      acc += v[0];
+#pragma unroll
+      for (int k = 1; k < 16; ++k) acc = fma(v[k], k < len ? 1.0 : 0.0, acc);
+      for (int u = u0 + 16; u < u1; u += 16) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = row[u + k];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc = fma(v[k], u + k < u1 ? 1.0 : 0.0, acc);
+      }
+      if (u1 >= nb) break;
+      u0 = u1;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) v[k] = vn[k];
     }
+    pe = pe_next;
+    pe_next = pe_next2;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) rv[m] = rv_next[m];
   }
   flush();
 }
