@@ -26,7 +26,7 @@ def main():
         t = np.frombuffer(buf, dtype=np.uint64).astype(np.int64)[:8]
         print("reduced_solve %.2f ms; last panel factorisation in shader cycles: load %d, 8 tile steps %d, store %d, inverse %d" % (
             ms, t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3]))
-        print("tile step 2: diagonal tile %d, panel %d, trailing (to end of step) ~%d" % (t[5] - t[7], t[6] - t[5], (t[2] - t[1]) // 8 - (t[6] - t[7])))
+        print("tile step 2: panel %d, trailing update beside the next diagonal tile %d" % (t[6] - t[5], t[7] - t[6]))
         return
     ms = dp.time_kernel(hipba.KERNEL_POINT_SCHUR, 5)
     print("point_schur %.1f us" % (1e3 * ms))

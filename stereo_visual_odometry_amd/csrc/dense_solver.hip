@@ -22,6 +22,7 @@ namespace hipba {
 
 constexpr int NB = kCholNB;  // 128
 typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));  // (arrays of HIP's double2 class are not promoted to registers)
 
 // ---- workspace -----------------------------------------------------------------------------------
 static size_t rup(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -91,11 +92,11 @@ __global__ void k_extract_z(DevP P, const double* A, int npad, int ld, double* z
 // operand slab of v_mfma_f64_16x16x4_f64 is 64 consecutive doubles).  Right-looking over the 8 tile
 // columns: wave 0 factors and inverts the 16x16 diagonal tile with scalar code, the panel below it and
 // the trailing tiles are updated on the matrix cores.  L^-1 is then built tile column by tile column
-// (block forward substitution), two tile columns per wave.
+// (block forward substitution), two tile columns per wave.  The workgroup that factors block k can ride in the
+// launch that updates the rest of the matrix with the previous panel(s): see potrf_block and the FUSE notes below.
 constexpr int TB = 16;
 constexpr int NTL = NB / TB;                      // 8 tile rows
 constexpr int kTile = TB * TB;                    // doubles per tile
-constexpr int kPotrfTiles = NTL * (NTL + 1) / 2 + NTL;  // L tiles + diagonal inverses
 
 __device__ __forceinline__ int ltile(int bi, int bj) { return (bi * (bi + 1) / 2 + bj) * kTile; }
 
@@ -138,21 +139,66 @@ __device__ __forceinline__ void tile_store_t(double* T, v4d v, int lane) {  // s
   for (int r = 0; r < 4; ++r) T[((lane >> 4) + 4 * r) * TB + (lane & 15)] = v[r];
 }
 
-template <int PH = 0xff>
-__global__ __launch_bounds__(256) void k_potrf_inv(DevP P, double* A, int ld, int k, double* Linv_all,
-                                                   double* LinvT_all) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  if (!P.ws[0].active || P.ws[0].solve_failed) return;
-  double* Lt = smem;                                   // 36 tiles
-  double* Dinv = smem + (NTL * (NTL + 1) / 2) * kTile;   // 8 tiles
-  int& fail = *reinterpret_cast<int*>(smem + kPotrfTiles * kTile);
-  double* rdiag = smem + kPotrfTiles * kTile + 8;        // [NB] reciprocals of the factor's diagonal
+// LDS of one panel factorisation: 36 lower tiles, the failure word, the reciprocal diagonal
+constexpr size_t kPotrfLds = (size_t)(NTL * (NTL + 1) / 2) * kTile * 8 + 64 + NB * 8;
+
+// Factorisation of diagonal block k by the calling workgroup (256 threads, kPotrfLds bytes at smem).
+// UPD: the block is first brought up to date with panel columns [kcol0, kcol0 + K) of its own block row,
+//   A(k,k) -= L(k, cols) L(k, cols)^T, 64 columns per stage through LDS (the tile area doubles as the stage),
+//   so that the workgroup can run beside the kernel that applies the same update to the rest of the matrix.
+template <bool UPD, int PH = 0xff>
+__device__ __forceinline__ void potrf_block(const DevP& P, double* A, int ld, int k, double* Linv_all, double* LinvT_all,
+                                            double* smem, int kcol0, int K) {
+  double* Lt = smem;                                   // 36 tiles; the diagonal ones hold their inverses at the end
+  int& fail = *reinterpret_cast<int*>(smem + (NTL * (NTL + 1) / 2) * kTile);
+  double* rdiag = smem + (NTL * (NTL + 1) / 2) * kTile + 8;  // [NB] reciprocals of the factor's diagonal
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   double* Akk = A + (long long)k * NB * ld + (long long)k * NB;
   HIPBA_CYCLES(0);
-  // load the lower tiles: thread t carries element (row t & 15, column t >> 4) of every tile, so the 36
-  // loads are independent and each wave reads 128-byte runs
-  {
+  if (UPD) {
+    // wave w owns tile rows w and 7 - w of the lower triangle: nine tiles, accumulated (negated, transposed:
+    // register r of lane l is element (l & 15, (l >> 4) + 4 r)) over all stages.  The products are bound by the
+    // one CU's matrix cores (about 12 us for K = 128); variants with operand reuse or software pipelining of
+    // the LDS reads only added instructions and measured slower.
+    v4d acc[9];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) acc[e] = (v4d){0.0, 0.0, 0.0, 0.0};
+    const double* pan = A + (long long)kcol0 * ld + (long long)k * NB;  // rows of block k, first panel column
+    const int q = t >> 4, pr = t & 15;
+    double stage[32];  // thread t carries element (pr, q) of each of the 8 x 4 stage tiles
+#define HIPBA_STAGE_LOAD(s_)                                                                     \
+  _Pragma("unroll") for (int i = 0; i < NTL; ++i) _Pragma("unroll") for (int kt = 0; kt < 4; ++kt) \
+      stage[4 * i + kt] = pan[(long long)(64 * (s_) + TB * kt + q) * ld + TB * i + pr];
+    const int nstage = K / 64;
+    HIPBA_STAGE_LOAD(0);
+    for (int sidx = 0; sidx < nstage; ++sidx) {
+      if (sidx) __syncthreads();  // the previous stage's products are done with the tiles
+#pragma unroll
+      for (int i = 0; i < 32; ++i) Lt[i * kTile + t] = stage[i];
+      __syncthreads();
+      if (sidx + 1 < nstage) HIPBA_STAGE_LOAD(sidx + 1);
+#pragma unroll
+      for (int e = 0; e < 9; ++e) {
+        const int i = e <= wave ? wave : NTL - 1 - wave, j = e <= wave ? e : e - wave - 1;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+          acc[e] = mfma_tile<true>(Lt + (4 * j + kt) * kTile, Lt + (4 * i + kt) * kTile, acc[e], lane);
+      }
+    }
+#undef HIPBA_STAGE_LOAD
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 9; ++e) {
+      const int i = e <= wave ? wave : NTL - 1 - wave, j = e <= wave ? e : e - wave - 1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int col = (lane >> 4) + 4 * r, row = lane & 15;
+        Lt[ltile(i, j) + col * TB + row] = Akk[(long long)(TB * j + col) * ld + TB * i + row] + acc[e][r];
+      }
+    }
+  } else {
+    // load the lower tiles: thread t carries element (row t & 15, column t >> 4) of every tile, so the 36
+    // loads are independent and each wave reads 128-byte runs
     const int q = t >> 4, pr = t & 15;
 #pragma unroll
     for (int bi = 0; bi < NTL; ++bi)
@@ -163,42 +209,42 @@ __global__ __launch_bounds__(256) void k_potrf_inv(DevP P, double* A, int ld, in
   __syncthreads();
   HIPBA_CYCLES(1);
 
-  for (int j = 0; j < NTL; ++j) {
-    if (j == 2) HIPBA_CYCLES(7);
-    if (wave == 0 && (PH & 1)) {
-      // (a) Cholesky of the 16x16 diagonal tile in registers: lane r holds row r, the pivots and multipliers
-      // travel between lanes as wave-uniform scalars (v_readlane).  The tile's inverse is not needed inside
-      // the loop (the panel below is solved by substitution) and is formed for all eight tiles at once later.
-      double* D = Lt + ltile(j, j);
-      const int r = lane & 15;
-      double x[TB], rinv[TB];
+  // (a) Cholesky of the 16x16 diagonal tile jd by one wave, in registers: lane r holds row r, the pivots and
+  // multipliers travel between lanes as wave-uniform scalars (v_readlane).  The tile's inverse is not needed
+  // inside the loop (the panel below is solved by substitution) and is formed for all eight tiles at once later.
+  auto diag_tile = [&](int jd) {
+    double* D = Lt + ltile(jd, jd);
+    const int r = lane & 15;
+    double x[TB], rinv[TB];
 #pragma unroll
-      for (int c = 0; c < TB; ++c) x[c] = D[c * TB + r];
-      bool bad = false;
+    for (int c = 0; c < TB; ++c) x[c] = D[c * TB + r];
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < TB; ++c) {
+      const double d = bcast_lane(x[c], c);
+      if (!(d > 0.0) || !isfinite(d)) bad = true;
+      // 1/sqrt(d): hardware estimate + two Newton steps (full double precision, no division)
+      double inv = __builtin_amdgcn_rsq(d);
+      inv = inv * (1.5 - 0.5 * d * inv * inv);
+      inv = inv * (1.5 - 0.5 * d * inv * inv);
+      rinv[c] = inv;
+      x[c] *= inv;
+#pragma unroll
+      for (int kc = c + 1; kc < TB; ++kc) x[kc] -= x[c] * bcast_lane(x[c], kc);
+    }
+    if (bad) {
+      if (lane == 0) fail = 1;
+    } else if (lane < TB) {
 #pragma unroll
       for (int c = 0; c < TB; ++c) {
-        const double d = bcast_lane(x[c], c);
-        if (!(d > 0.0) || !isfinite(d)) bad = true;
-        // 1/sqrt(d): hardware estimate + two Newton steps (full double precision, no division)
-        double inv = __builtin_amdgcn_rsq(d);
-        inv = inv * (1.5 - 0.5 * d * inv * inv);
-        inv = inv * (1.5 - 0.5 * d * inv * inv);
-        rinv[c] = inv;
-        x[c] *= inv;
-#pragma unroll
-        for (int kc = c + 1; kc < TB; ++kc) x[kc] -= x[c] * bcast_lane(x[c], kc);
-      }
-      if (bad) {
-        if (lane == 0) fail = 1;
-      } else if (lane < TB) {
-#pragma unroll
-        for (int c = 0; c < TB; ++c) {
-          if (c <= r) D[c * TB + r] = x[c];
-          if (c == r) rdiag[j * TB + c] = rinv[c];
-        }
+        if (c <= r) D[c * TB + r] = x[c];
+        if (c == r) rdiag[jd * TB + c] = rinv[c];
       }
     }
-    __syncthreads();
+  };
+  if (wave == 0 && (PH & 1)) diag_tile(0);
+  __syncthreads();
+  for (int j = 0; j < NTL; ++j) {
     if (j == 2) HIPBA_CYCLES(5);
     if (fail) break;
     // (b) panel below the diagonal tile: L(i,j) = A(i,j) L(j,j)^-T, one lane per row, forward substitution with
@@ -210,24 +256,38 @@ __global__ __launch_bounds__(256) void k_potrf_inv(DevP P, double* A, int ld, in
       double x[TB];
 #pragma unroll
       for (int c = 0; c < TB; ++c) x[c] = T[c * TB];
+      // right-looking: a finished column is taken out of all later ones at once (independent multiply-adds;
+      // the dependency chain is two operations per column instead of one per term)
 #pragma unroll
       for (int c = 0; c < TB; ++c) {
-        double v = x[c];
+        x[c] *= ri[c];
 #pragma unroll
-        for (int t2 = 0; t2 < c; ++t2) v -= x[t2] * D[t2 * TB + c];
-        x[c] = v * ri[c];
+        for (int c2 = c + 1; c2 < TB; ++c2) x[c2] -= x[c] * D[c * TB + c2];
       }
 #pragma unroll
       for (int c = 0; c < TB; ++c) T[c * TB] = x[c];
     }
     __syncthreads();
     if (j == 2) HIPBA_CYCLES(6);
-    // (c) trailing tiles: A(i2,j2) -= L(i2,j) L(j2,j)^T, again held transposed in the accumulator
-    {
+    // (c) trailing tiles: A(i2,j2) -= L(i2,j) L(j2,j)^T, again held transposed in the accumulator.  Wave 0 takes
+    // the next diagonal tile alone and factors it at once (the longest single-wave job of a step) while the
+    // other three waves share the remaining tiles.
+    if (wave == 0) {
+      if (j + 1 < NTL && (PH & 4)) {
+        double* C = Lt + ltile(j + 1, j + 1);
+        v4d acc = tile_load_t(C, lane);
+        acc = mfma_tile<true>(Lt + ltile(j + 1, j), Lt + ltile(j + 1, j), acc, lane);
+        tile_store_t(C, acc, lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (PH & 1) diag_tile(j + 1);
+      }
+    } else {
       int e = 0;
-      for (int i2 = j + 1; i2 < NTL && (PH & 4); ++i2) {
+      for (int i2 = j + 2; i2 < NTL && (PH & 4); ++i2) {
         for (int j2 = j + 1; j2 <= i2; ++j2, ++e) {
-          if ((e & 3) != wave) continue;
+          if (e % 3 != wave - 1) continue;
           double* C = Lt + ltile(i2, j2);
           v4d acc = tile_load_t(C, lane);
           acc = mfma_tile<true>(Lt + ltile(j2, j), Lt + ltile(i2, j), acc, lane);
@@ -236,6 +296,7 @@ __global__ __launch_bounds__(256) void k_potrf_inv(DevP P, double* A, int ld, in
       }
     }
     __syncthreads();
+    if (j == 2) HIPBA_CYCLES(7);
   }
   HIPBA_CYCLES(2);
   if (fail) {
@@ -252,21 +313,27 @@ __global__ __launch_bounds__(256) void k_potrf_inv(DevP P, double* A, int ld, in
         if (bi > bj || pr >= q) Akk[(long long)(TB * bj + q) * ld + TB * bi + pr] = Lt[ltile(bi, bj) + t];
   }
   // inverses of the eight diagonal tiles, all at once: 16 lanes per tile, lane r forms column r by forward
-  // substitution with the tile read from LDS
-  if (wave < 2) {
+  // substitution with the tile read from LDS; the inverse then replaces the tile (the factor is already out)
+  {
     const int tl = wave * 4 + (lane >> 4), r = lane & 15;
-    const double* D = Lt + ltile(tl, tl);
-    const double* ri = rdiag + tl * TB;
     double y[TB];
+    if (wave < 2) {
+      const double* D = Lt + ltile(tl, tl);
+      const double* ri = rdiag + tl * TB;
 #pragma unroll
-    for (int i = 0; i < TB; ++i) {
-      double acc = (i == r) ? 1.0 : 0.0;
+      for (int i = 0; i < TB; ++i) y[i] = (i == r) ? 1.0 : 0.0;
 #pragma unroll
-      for (int tt = 0; tt < i; ++tt) acc -= D[tt * TB + i] * y[tt];
-      y[i] = acc * ri[i];
+      for (int tt = 0; tt < TB; ++tt) {
+        y[tt] *= ri[tt];
+#pragma unroll
+        for (int i = tt + 1; i < TB; ++i) y[i] -= D[tt * TB + i] * y[tt];
+      }
     }
+    __syncthreads();
+    if (wave < 2) {
 #pragma unroll
-    for (int c = 0; c < TB; ++c) Dinv[tl * kTile + r * TB + c] = y[c];
+      for (int c = 0; c < TB; ++c) Lt[ltile(tl, tl) + r * TB + c] = y[c];
+    }
   }
   __syncthreads();
   HIPBA_CYCLES(3);
@@ -288,7 +355,7 @@ __global__ __launch_bounds__(256) void k_potrf_inv(DevP P, double* A, int ld, in
       }
     }
     v4d xs[NTL];  // X(j + rel, j), rel = 0 .. 7 - j
-    xs[0] = tile_load(Dinv + j * kTile, lane);
+    xs[0] = tile_load(Lt + ltile(j, j), lane);
 #pragma unroll
     for (int rel = 0; rel < NTL; ++rel) {
       const int i = j + rel;
@@ -303,7 +370,7 @@ __global__ __launch_bounds__(256) void k_potrf_inv(DevP P, double* A, int ld, in
               y = __builtin_amdgcn_mfma_f64_16x16x4f64(M[(kk * 4 + (lane >> 4)) * TB + (lane & 15)], xs[rt][kk], y, 0, 0, 0);
           }
           v4d x = (v4d){0.0, 0.0, 0.0, 0.0};
-          const double* Di = Dinv + i * kTile;
+          const double* Di = Lt + ltile(i, i);
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk)
             x = __builtin_amdgcn_mfma_f64_16x16x4f64(-Di[(kk * 4 + (lane >> 4)) * TB + (lane & 15)], y[kk], x, 0, 0, 0);
@@ -321,6 +388,14 @@ __global__ __launch_bounds__(256) void k_potrf_inv(DevP P, double* A, int ld, in
   HIPBA_CYCLES(4);
 }
 
+template <int PH = 0xff>
+__global__ __launch_bounds__(256) void k_potrf_inv(DevP P, double* A, int ld, int k, double* Linv_all,
+                                                   double* LinvT_all) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  if (!P.ws[0].active || P.ws[0].solve_failed) return;
+  potrf_block<false, PH>(P, A, ld, k, Linv_all, LinvT_all, smem, 0, 0);
+}
+
 // ---- fp64 matrix-core GEMM, C(i,j) (op)= sum_k A(i,k) B(j,k), column-major, 128x128 tiles ----------
 // MODE 0: update        A(i,j) -= sum over panel columns [kcol, kcol + K) of L(i,k) L(j,k)
 //                       (1-D grid over the tiles (i0 + r, j0 + c), c <= r < m, plus row m in full)
@@ -331,12 +406,22 @@ __global__ __launch_bounds__(256) void k_potrf_inv(DevP P, double* A, int ld, in
 constexpr int KC = 16;            // k-depth of one LDS stage
 constexpr int LDT = 128 + 16;     // LDS row pitch (doubles): the two k-groups of a half-wave land 32 banks apart
 
+// FUSE (MODE 0, fuse_linv != null): workgroup 0, which owns the diagonal tile (i0, j0), brings that tile up to
+// date itself and goes on to factor it (potrf_block): the next panel factorisation, one workgroup's work on the
+// critical path, runs beside this launch's other tiles instead of after them.
+constexpr size_t kGemmNtLds = (size_t)4 * KC * LDT * 8;
 template <int MODE>
-__global__ __launch_bounds__(256, 2) void k_gemm_nt(DevP P, double* Amat, int ld, int i0, int j0, int kcol, int K,
-                                                 const double* Linv, long long Linv_or_m) {
-  __shared__ __attribute__((aligned(16))) double sA[2][KC * LDT];  // i-tile
-  __shared__ __attribute__((aligned(16))) double sB[2][KC * LDT];  // j-tile
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm_nt(DevP P, double* Amat, int ld, int i0, int j0, int kcol, int K,
+                                                 const double* Linv, long long Linv_or_m, double* fuse_linv,
+                                                 double* fuse_linvt) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double (*sA)[KC * LDT] = reinterpret_cast<double (*)[KC * LDT]>(smem);                 // i-tile, two stages
+  double (*sB)[KC * LDT] = reinterpret_cast<double (*)[KC * LDT]>(smem + 2 * KC * LDT);  // j-tile
   if (!P.ws[0].active || P.ws[0].solve_failed) return;
+  if (MODE == 0 && fuse_linv && blockIdx.x == 0) {
+    potrf_block<true>(P, Amat, ld, i0, fuse_linv, fuse_linvt, smem, kcol, K);
+    return;
+  }
   int ti, tj;
   if (MODE == 0) {
     // One workgroup per tile of the lower triangle of an m x m tile grid (row by row), then one per tile of an
@@ -449,17 +534,25 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(DevP P, double* Amat, int ld
 // factorisations; with one LDS stage in flight they were bound by eight back-to-back load latencies.  Here the
 // k-loop is fully unrolled and DEPTH stages of global loads are in flight at any time (all eight for the
 // 64x64 update, whose destination tile is fetched up front as well).
+// FUSE (MODE 0, fuse_linv != null, launched with i0 == j0): workgroup (0, 0) updates the whole diagonal block
+// (i0, i0) itself and factors it (potrf_block); its three 64x64 tiles are skipped by the others.
 template <int MODE>
-__global__ __launch_bounds__(256, 2) void k_gemm_k128(DevP P, double* Amat, int ld, int i0, int j0, int kcol,
-                                                     const double* Linv) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm_k128(DevP P, double* Amat, int ld, int i0, int j0, int kcol,
+                                                     const double* Linv, double* fuse_linv, double* fuse_linvt) {
   constexpr int TI = 64, TJ = MODE == 0 ? 64 : NB;
   constexpr int LDA = TI + 16, LDB = TJ + 16;
   constexpr int PA = TI / 16, PB = TJ / 16;    // doubles per thread and stage
   constexpr int MI = TI / 32, MJ = TJ / 32;    // 16x16 sub-tiles per wave
   constexpr int NCH = NB / KC;                 // 8 stages
   constexpr int DEPTH = MODE == 0 ? 8 : 4;     // stages of global loads in flight
-  __shared__ __attribute__((aligned(16))) double sA[2][KC * LDA];
-  __shared__ __attribute__((aligned(16))) double sB[2][KC * LDB];
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double (*sA)[KC * LDA] = reinterpret_cast<double (*)[KC * LDA]>(smem);
+  double (*sB)[KC * LDB] = reinterpret_cast<double (*)[KC * LDB]>(smem + 2 * KC * LDA);
+  if (MODE == 0 && fuse_linv && blockIdx.x < 2 && blockIdx.y < 2) {
+    if (blockIdx.x == 0 && blockIdx.y == 0 && P.ws[0].active && !P.ws[0].solve_failed)
+      potrf_block<true>(P, Amat, ld, i0, fuse_linv, fuse_linvt, smem, kcol, NB);
+    return;
+  }
   const int row0 = i0 * NB + blockIdx.x * TI;
   const int col0 = MODE == 0 ? j0 * NB + blockIdx.y * TJ : 0;
   if (MODE == 0 && col0 > row0 + TI - 1) return;  // wholly above the diagonal
@@ -471,16 +564,17 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k128(DevP P, double* Amat, int 
   const int ldb = MODE == 0 ? ld : NB;
   double* Cp = MODE == 0 ? Amat + (long long)col0 * ld + row0 : Amat + (long long)kcol * ld + row0;
 
-  double2 ra[DEPTH][PA / 2], rb[DEPTH][PB / 2];
+  v2d ra[DEPTH][PA / 2], rb[DEPTH][PB / 2];
 #define K128_GLOAD(slot, chunk)                                                                                   \
   {                                                                                                               \
-    const double2* a_ = reinterpret_cast<const double2*>(Ap + (long long)((chunk)*KC + lcol) * ld + lsub * PA);   \
-    const double2* b_ = reinterpret_cast<const double2*>(Bp + (long long)((chunk)*KC + lcol) * ldb + lsub * PB);  \
+    const v2d* a_ = reinterpret_cast<const v2d*>(Ap + (long long)((chunk)*KC + lcol) * ld + lsub * PA);   \
+    const v2d* b_ = reinterpret_cast<const v2d*>(Bp + (long long)((chunk)*KC + lcol) * ldb + lsub * PB);  \
     _Pragma("unroll") for (int m = 0; m < PA / 2; ++m) ra[slot][m] = a_[m];                                       \
     _Pragma("unroll") for (int m = 0; m < PB / 2; ++m) rb[slot][m] = b_[m];                                       \
   }
-#pragma unroll
-  for (int c = 0; c < DEPTH; ++c) K128_GLOAD(c, c);
+  // (stage indices are written out as literals: with a loop counter the staging registers ended up in scratch)
+  K128_GLOAD(0, 0); K128_GLOAD(1, 1); K128_GLOAD(2, 2); K128_GLOAD(3, 3);
+  if constexpr (DEPTH == 8) { K128_GLOAD(4, 4); K128_GLOAD(5, 5); K128_GLOAD(6, 6); K128_GLOAD(7, 7); }
   // destination tile (MODE 0): fetched now, used after the last stage
   double cold[MJ][MI][4];
   if (MODE == 0) {
@@ -501,33 +595,29 @@ __global__ __launch_bounds__(256, 2) void k_gemm_k128(DevP P, double* Amat, int 
     for (int b = 0; b < MI; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
   if (!live) return;
 
-#pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    const int buf = c & 1, slot = c % DEPTH;
-    {
-      double2* a_ = reinterpret_cast<double2*>(&sA[buf][lcol * LDA + lsub * PA]);
-      double2* b_ = reinterpret_cast<double2*>(&sB[buf][lcol * LDB + lsub * PB]);
-#pragma unroll
-      for (int m = 0; m < PA / 2; ++m) a_[m] = ra[slot][m];
-#pragma unroll
-      for (int m = 0; m < PB / 2; ++m) b_[m] = rb[slot][m];
-    }
-    __syncthreads();  // stage c visible; everybody is past the reads of stage c - 2, which shared this buffer
-    if (c + DEPTH < NCH) K128_GLOAD(slot, c + DEPTH);
-#pragma unroll
-    for (int kk = 0; kk < KC / 4; ++kk) {
-      const int kr = kk * 4 + (lane >> 4);
-      double fa[MJ], fb[MI];
-#pragma unroll
-      for (int m = 0; m < MJ; ++m) fa[m] = sB[buf][kr * LDB + (lane & 15) + wc * (TJ / 2) + m * 16];
-#pragma unroll
-      for (int m = 0; m < MI; ++m) fb[m] = sA[buf][kr * LDA + (lane & 15) + wr * (TI / 2) + m * 16];
-#pragma unroll
-      for (int a = 0; a < MJ; ++a)
-#pragma unroll
-        for (int b = 0; b < MI; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
-    }
+#define K128_STAGE(c)                                                                                             \
+  {                                                                                                               \
+    constexpr int buf = (c) & 1, slot = (c) % DEPTH;                                                              \
+    {                                                                                                             \
+      v2d* a_ = reinterpret_cast<v2d*>(&sA[buf][lcol * LDA + lsub * PA]);                                 \
+      v2d* b_ = reinterpret_cast<v2d*>(&sB[buf][lcol * LDB + lsub * PB]);                                 \
+      _Pragma("unroll") for (int m = 0; m < PA / 2; ++m) a_[m] = ra[slot][m];                                     \
+      _Pragma("unroll") for (int m = 0; m < PB / 2; ++m) b_[m] = rb[slot][m];                                     \
+    }                                                                                                             \
+    __syncthreads(); /* stage c visible; everybody is past the reads of stage c - 2, which shared this buffer */  \
+    if constexpr ((c) + DEPTH < NCH) K128_GLOAD(slot, (c) + DEPTH);                                               \
+    _Pragma("unroll") for (int kk = 0; kk < KC / 4; ++kk) {                                                       \
+      const int kr = kk * 4 + (lane >> 4);                                                                        \
+      double fa[MJ], fb[MI];                                                                                      \
+      _Pragma("unroll") for (int m = 0; m < MJ; ++m) fa[m] = sB[buf][kr * LDB + (lane & 15) + wc * (TJ / 2) + m * 16]; \
+      _Pragma("unroll") for (int m = 0; m < MI; ++m) fb[m] = sA[buf][kr * LDA + (lane & 15) + wr * (TI / 2) + m * 16]; \
+      _Pragma("unroll") for (int a = 0; a < MJ; ++a) _Pragma("unroll") for (int b = 0; b < MI; ++b)               \
+          acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);                     \
+    }                                                                                                             \
   }
+  K128_STAGE(0) K128_STAGE(1) K128_STAGE(2) K128_STAGE(3) K128_STAGE(4) K128_STAGE(5) K128_STAGE(6) K128_STAGE(7)
+  static_assert(NCH == 8, "the stages are written out");
+#undef K128_STAGE
 #undef K128_GLOAD
 #pragma unroll
   for (int a = 0; a < MJ; ++a) {
@@ -623,10 +713,20 @@ __global__ void k_store_solution(DevP P, const double* y, int n) {
 }
 
 hipError_t big_solve_cholesky(const DevP& P, const BigWork& W, hipStream_t s) {
+  constexpr size_t kLdsTrsm = (size_t)(2 * KC * (64 + 16) + 2 * KC * (NB + 16)) * 8;
+  constexpr size_t kLdsK128 = (size_t)(4 * KC * (64 + 16)) * 8;
+  constexpr size_t kLdsK128Fused = kLdsK128 > kPotrfLds ? kLdsK128 : kPotrfLds;
+  constexpr size_t kLdsNtFused = kGemmNtLds > kPotrfLds ? kGemmNtLds : kPotrfLds;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_potrf_inv<0xff>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024);
+                              (int)kPotrfLds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_k128<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)kLdsK128Fused);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_k128<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)kLdsTrsm);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_nt<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)kLdsNtFused);
     attr_done = true;
   }
   const int n = W.n, npad = W.npad, nt = npad / NB;
@@ -634,29 +734,29 @@ hipError_t big_solve_cholesky(const DevP& P, const BigWork& W, hipStream_t s) {
   const int ncam = n / 6;
   hipLaunchKernelGGL(k_unpack_lower, dim3((ncam * 36 + 255) / 256, ncam), dim3(256), 0, s, P, W.A, ld);
   hipLaunchKernelGGL(k_pad_init, dim3((npad + 255) / 256), dim3(256), 0, s, P, W.A, n, npad, ld);
-  const size_t lds = (size_t)kPotrfTiles * kTile * 8 + 64 + NB * 8;
   // Two-level right-looking factorisation.  Panels of 128 columns are grouped in blocks of kOuter
   // panels.  Inside a block a freshly factored panel only updates the block's remaining panel columns
   // (narrow updates, K = 128); the rest of the trailing matrix is updated once per block with
   // K = kOuter * 128, which divides the read-modify-write traffic of the trailing tiles by kOuter.
-  // (Overlapping that update with the next block's panel chain on a second stream was measured and
-  // lost 5 %: the panel kernels then queue behind 50 us trailing-update workgroups.)
+  // Look-ahead by fusion: the workgroup that owns the next diagonal block in an update launch factors it right
+  // there, so only the very first panel factorisation is a launch of its own.  (Overlapping through a second
+  // stream was measured and lost 5 %: the panel kernels queue behind 50 us trailing-update workgroups.)
   // Row tiles run to nt inclusive: tile row nt is the right-hand side.
   constexpr int kOuter = 8;  // 6 and 8 measure the same; 4 and 10+ are slower
+  hipLaunchKernelGGL(k_potrf_inv<0xff>, dim3(1), dim3(256), kPotrfLds, s, P, W.A, ld, 0, W.Linv, W.LinvT);
   for (int p0 = 0; p0 < nt; p0 += kOuter) {
     const int p1 = p0 + kOuter < nt ? p0 + kOuter : nt;
     for (int p = p0; p < p1; ++p) {
-      hipLaunchKernelGGL(k_potrf_inv<0xff>, dim3(1), dim3(256), lds, s, P, W.A, ld, p, W.Linv, W.LinvT);
-      hipLaunchKernelGGL(k_gemm_k128<1>, dim3(2 * (nt - p - 1) + 1, 1), dim3(256), 0, s, P, W.A, ld, p + 1, 0, p * NB,
-                         (const double*)(W.Linv + (long long)p * NB * NB));
-      if (p + 1 < p1)  // bring the block's remaining panel columns up to date with panel p (K = 128)
-        hipLaunchKernelGGL(k_gemm_k128<0>, dim3(2 * (nt - p - 1) + 1, 2 * (p1 - p - 1)), dim3(256), 0, s, P, W.A, ld,
-                           p + 1, p + 1, p * NB, (const double*)nullptr);
+      hipLaunchKernelGGL(k_gemm_k128<1>, dim3(2 * (nt - p - 1) + 1, 1), dim3(256), kLdsTrsm, s, P, W.A, ld, p + 1, 0,
+                         p * NB, (const double*)(W.Linv + (long long)p * NB * NB), (double*)nullptr, (double*)nullptr);
+      if (p + 1 < p1)  // bring the block's remaining panel columns up to date with panel p (K = 128); factor p + 1
+        hipLaunchKernelGGL(k_gemm_k128<0>, dim3(2 * (nt - p - 1) + 1, 2 * (p1 - p - 1)), dim3(256), kLdsK128Fused, s, P,
+                           W.A, ld, p + 1, p + 1, p * NB, (const double*)nullptr, W.Linv, W.LinvT);
     }
     const int rest = nt - p1;
-    if (rest > 0)
-      hipLaunchKernelGGL(k_gemm_nt<0>, dim3(rest * (rest + 1) / 2 + rest), dim3(256), 0, s, P, W.A, ld, p1, p1, p0 * NB,
-                         (p1 - p0) * NB, (const double*)nullptr, (long long)rest);
+    if (rest > 0)  // trailing update with the whole block (K = kOuter * 128); factor panel p1
+      hipLaunchKernelGGL(k_gemm_nt<0>, dim3(rest * (rest + 1) / 2 + rest), dim3(256), kLdsNtFused, s, P, W.A, ld, p1, p1,
+                         p0 * NB, (p1 - p0) * NB, (const double*)nullptr, (long long)rest, W.Linv, W.LinvT);
   }
   double* z = W.rhs + npad;
   hipLaunchKernelGGL(k_extract_z, dim3((npad + 255) / 256), dim3(256), 0, s, P, (const double*)W.A, npad, ld, z);
