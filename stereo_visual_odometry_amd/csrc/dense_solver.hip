@@ -742,7 +742,9 @@ hipError_t big_solve_cholesky(const DevP& P, const BigWork& W, hipStream_t s) {
   // there, so only the very first panel factorisation is a launch of its own.  (Overlapping through a second
   // stream was measured and lost 5 %: the panel kernels queue behind 50 us trailing-update workgroups.)
   // Row tiles run to nt inclusive: tile row nt is the right-hand side.
-  constexpr int kOuter = 8;  // 6 and 8 measure the same; 4 and 10+ are slower
+  // Block size: with the panel factorisations hidden in the narrow updates, wide blocks win -- measured at 94
+  // panels: 8 -> 18.8 ms, 16 -> 17.7, 24 -> 17.7, 32 -> 17.0, 47 -> 19.3 (30 and 34-40: 18.3-19.1).
+  const int kOuter = nt >= 64 ? 32 : (nt >= 24 ? 16 : 8);
   hipLaunchKernelGGL(k_potrf_inv<0xff>, dim3(1), dim3(256), kPotrfLds, s, P, W.A, ld, 0, W.Linv, W.LinvT);
   for (int p0 = 0; p0 < nt; p0 += kOuter) {
     const int p1 = p0 + kOuter < nt ? p0 + kOuter : nt;
