@@ -529,22 +529,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 // ---- the K = 128 steps of the panel chain ------------------------------------------------------------------
 // Same products as k_gemm_nt, for one panel (K = NB) and 64-row tiles:
-//   MODE 0: A(i,j) -= L(i,k) L(j,k)^T on 64x64 tiles,   MODE 1: L(i,k) = A(i,k) Linv(k)^T on 64x128 tiles.
+//   MODE 0: A(i,j) -= L(i,k) L(j,k)^T on 64x64 tiles,   MODE 1: L(i,k) = A(i,k) Linv(k)^T on 32x128 tiles.
 // These launches are short (a few hundred tiles, 4 MFLOP each) and sit on the critical path between two panel
 // factorisations; with one LDS stage in flight they were bound by eight back-to-back load latencies.  Here the
 // k-loop is fully unrolled and DEPTH stages of global loads are in flight at any time (all eight for the
 // 64x64 update, whose destination tile is fetched up front as well).
 // FUSE (MODE 0, fuse_linv != null, launched with i0 == j0): workgroup (0, 0) updates the whole diagonal block
 // (i0, i0) itself and factors it (potrf_block); its three 64x64 tiles are skipped by the others.
+constexpr int kTrsmRows = 32;  // rows per workgroup of the panel solve: 32 -> twice the workgroups of 64, all stages in flight
 template <int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm_k128(DevP P, double* Amat, int ld, int i0, int j0, int kcol,
                                                      const double* Linv, double* fuse_linv, double* fuse_linvt) {
-  constexpr int TI = 64, TJ = MODE == 0 ? 64 : NB;
+  constexpr int TI = MODE == 0 ? 64 : kTrsmRows, TJ = MODE == 0 ? 64 : NB;
   constexpr int LDA = TI + 16, LDB = TJ + 16;
   constexpr int PA = TI / 16, PB = TJ / 16;    // doubles per thread and stage
   constexpr int MI = TI / 32, MJ = TJ / 32;    // 16x16 sub-tiles per wave
   constexpr int NCH = NB / KC;                 // 8 stages
-  constexpr int DEPTH = MODE == 0 ? 8 : 4;     // stages of global loads in flight
+  constexpr int DEPTH = (MODE == 0 || TI <= 32) ? 8 : 4;  // stages of global loads in flight (register budget)
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double (*sA)[KC * LDA] = reinterpret_cast<double (*)[KC * LDA]>(smem);
   double (*sB)[KC * LDB] = reinterpret_cast<double (*)[KC * LDB]>(smem + 2 * KC * LDA);
@@ -635,11 +636,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   if (MODE == 1) {
     // L^T goes to the (unused) upper triangle so that the backward substitution reads columns too.  In the
-    // accumulators consecutive lanes hold consecutive ROWS of L; each wave turns its 32 x 64 block around in LDS,
+    // accumulators consecutive lanes hold consecutive ROWS of L; each wave turns its RW x 64 block around in LDS,
     // 32 columns at a time, so that consecutive lanes write consecutive columns (256-byte runs, not 8-byte ones).
     constexpr int TP = 33;                      // staging pitch (doubles): odd, no bank conflicts on the way back
+    constexpr int RW = TI / 2;                  // rows of a wave's block
     __syncthreads();                            // every wave is done reading the last stage
-    double* stg = &sB[0][0] + wave * 32 * TP;   // 4 x 8.4 KB inside sB
+    double* stg = &sB[0][0] + wave * RW * TP;   // at most 4 x 8.4 KB inside sB
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -654,11 +656,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      // 32 rows x 32 columns: lanes 0-31 take the columns of row rr, lanes 32-63 those of row rr + 1
+      // RW rows x 32 columns: lanes 0-31 take the columns of row rr, lanes 32-63 those of row rr + 1
 #pragma unroll
-      for (int rr = 0; rr < 32; rr += 2) {
+      for (int rr = 0; rr < RW; rr += 2) {
         const int rl = rr + (lane >> 5), cl = lane & 31;
-        Amat[(long long)(row0 + wr * 32 + rl) * ld + kcol + wc * 64 + half * 32 + cl] = stg[rl * TP + cl];
+        Amat[(long long)(row0 + wr * RW + rl) * ld + kcol + wc * 64 + half * 32 + cl] = stg[rl * TP + cl];
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -747,7 +749,7 @@ __global__ void k_store_solution(DevP P, const double* y, int n) {
 }
 
 hipError_t big_solve_cholesky(const DevP& P, const BigWork& W, hipStream_t s) {
-  constexpr size_t kLdsTrsm = (size_t)(2 * KC * (64 + 16) + 2 * KC * (NB + 16)) * 8;
+  constexpr size_t kLdsTrsm = (size_t)(2 * KC * (kTrsmRows + 16) + 2 * KC * (NB + 16)) * 8;
   constexpr size_t kLdsK128 = (size_t)(4 * KC * (64 + 16)) * 8;
   constexpr size_t kLdsK128Fused = kLdsK128 > kPotrfLds ? kLdsK128 : kPotrfLds;
   constexpr size_t kLdsNtFused = kGemmNtLds > kPotrfLds ? kGemmNtLds : kPotrfLds;
@@ -783,7 +785,7 @@ hipError_t big_solve_cholesky(const DevP& P, const BigWork& W, hipStream_t s) {
   for (int p0 = 0; p0 < nt; p0 += kOuter) {
     const int p1 = p0 + kOuter < nt ? p0 + kOuter : nt;
     for (int p = p0; p < p1; ++p) {
-      hipLaunchKernelGGL(k_gemm_k128<1>, dim3(2 * (nt - p - 1) + 1, 1), dim3(256), kLdsTrsm, s, P, W.A, ld, p + 1, 0,
+      hipLaunchKernelGGL(k_gemm_k128<1>, dim3((NB / kTrsmRows) * (nt - p - 1) + 1, 1), dim3(256), kLdsTrsm, s, P, W.A, ld, p + 1, 0,
                          p * NB, (const double*)(W.Linv + (long long)p * NB * NB), (double*)nullptr, (double*)nullptr);
       if (p + 1 < p1)  // bring the block's remaining panel columns up to date with panel p (K = 128); factor p + 1
         hipLaunchKernelGGL(k_gemm_k128<0>, dim3(2 * (nt - p - 1) + 1, 2 * (p1 - p - 1)), dim3(256), kLdsK128Fused, s, P,
