@@ -129,9 +129,11 @@ struct DevP {
   // and the two poses, so nothing per observation is kept in HBM.  Null when fp64 atomics are used instead.
   const uint2* pair_pt;           // [n_pairs] (landmark, (row slot << 16) | column slot)
   const uint2* pair_obs;          // [n_pairs] (observation i, observation j): where a robust loss reads its weights
-  const long long* chunk_start;   // [n_chunks + 1] pair ranges cut at destination boundaries, one wave each
+  const long long* chunk_start;   // [2 * n_chunks] (begin, end) pair ranges cut at destination boundaries, one wave
+                                  // each, longest first
   int n_chunks;
-  double* prec;                   // [16 * n_pm_points] landmark record: p (3), scale_p (3), V^-1 (6), 4 unused
+  double* prec;                   // [16 * n_pm_points] landmark record, one 128-byte line: p (3), scale_p (3),
+                                  // V^-1 (6), scale_p o (V^-1 g_p) (3), one unused
   double* fw;                     // [n_pm_obs] sqrt(rho') of every observation (robust loss only)
   double* cam_tab;                // [18 * n_act_poses] R^T (9), R^T t (3), scale_c (6) of every variable pose
   const WinDesc* wd;
@@ -145,7 +147,6 @@ struct DevP {
   double* Vinv;     // [6*n_pm_points]  (V + D^2)^-1, symmetric packing
   double* gp;       // [3*n_pm_points]  scaled landmark gradient
   double* scale_p;  // [3*n_pm_points]
-  double* vg;       // [3*n_pm_points]  scale_p o (V^-1 g_p), gathered mode only
   double* S;        // packed upper block-triangular reduced matrices, 36 doubles per 6x6 block
   double* partial;  // [2 banks][kPartialStride * n_blocks]
   double* gpart;    // [2 * n_blk_pm] landmark gradient max / sum of squares per PM block

@@ -428,11 +428,18 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
     }
     // one wave per chunk of about kGatherChunk pairs; a chunk holds whole destinations, so every block of S
     // has exactly one writer
+    // (begin, end) per chunk, longest first: a diagonal block alone has as many pairs as its camera has
+    // observations, and such a chunk started last would be the tail of the launch
     const long long kGatherChunk = 1024;
-    chunk_start.push_back(0);
+    std::vector<std::pair<long long, long long>> chunks;
+    long long cbeg = 0;
     for (long long dd = 0; dd < n_dest; ++dd)
-      if (dest_start[dd + 1] - chunk_start.back() >= kGatherChunk) chunk_start.push_back(dest_start[dd + 1]);
-    if (chunk_start.back() != dest_start[n_dest]) chunk_start.push_back(dest_start[n_dest]);
+      if (dest_start[dd + 1] - cbeg >= kGatherChunk) { chunks.emplace_back(cbeg, dest_start[dd + 1]); cbeg = dest_start[dd + 1]; }
+    if (cbeg != dest_start[n_dest]) chunks.emplace_back(cbeg, dest_start[n_dest]);
+    std::stable_sort(chunks.begin(), chunks.end(), [](const std::pair<long long, long long>& x, const std::pair<long long, long long>& y) {
+      return x.second - x.first > y.second - y.first;
+    });
+    for (const auto& c : chunks) { chunk_start.push_back(c.first); chunk_start.push_back(c.second); }
     pairs.assign(8, kPairPad);  // the blocks themselves need no pair lists in this mode
   }
 
@@ -621,7 +628,7 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   work.add(&P.wsum, (size_t)8 * nw);
   work.add(&P.log, (size_t)std::max(log_cap, 1) * nw);
   work.add(&R->d_count, 4);
-  if (staged) { work.add(&P.prec, 16 * npp); work.add(&P.fw, (size_t)n_pm_obs); work.add(&P.cam_tab, 18 * ns); work.add(&P.vg, 3 * npp); }
+  if (staged) { work.add(&P.prec, 16 * npp); work.add(&P.fw, (size_t)n_pm_obs); work.add(&P.cam_tab, 18 * ns); }
   char* big_base_dummy = nullptr;
   size_t big_bytes = 0;
   if (6 * max_ncam > kSmallMaxN) {
@@ -657,8 +664,8 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   P.obs_pose = d_obs_pose; P.obs_dp = d_obs_dp; P.obs_uv = d_obs_uv; P.pp_obs_start = d_pp_start;
   P.blocks = d_blocks; P.pairs = d_pairs; P.wd = d_wd; P.runs = d_runs;
   P.pair_obs = d_pair_obs; P.pair_pt = d_pair_pt; P.chunk_start = d_chunk_start;
-  P.n_chunks = staged ? (int)chunk_start.size() - 1 : 0;
-  if (!staged) { P.prec = nullptr; P.fw = nullptr; P.cam_tab = nullptr; P.vg = nullptr; }
+  P.n_chunks = staged ? (int)(chunk_start.size() / 2) : 0;
+  if (!staged) { P.prec = nullptr; P.fw = nullptr; P.cam_tab = nullptr; }
 
   char* st = static_cast<char*>(h->staging);
   auto stage = [&](const void* dev_ptr, const void* src, size_t bytes) {

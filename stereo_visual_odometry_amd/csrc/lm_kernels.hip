@@ -194,7 +194,7 @@ __global__ __launch_bounds__(kBlock) void k_camera_blocks(DevP P, LmParams lm, i
 }
 
 // reduced right-hand side, camera by camera: b_c -= sum over the camera's observations of variable landmarks of
-// Jc^T Jp V^-1 g_p (= Y g_p), with V^-1 g_p as k_point_schur left it in vg.  One workgroup and one writer per
+// Jc^T Jp V^-1 g_p (= Y g_p), with V^-1 g_p as k_point_schur left it in the landmark's record.  One workgroup and one writer per
 // pose: no atomics, fixed order.  Used with the gathered accumulation of S.
 __global__ __launch_bounds__(kBlock) void k_camera_rhs(DevP P, LmParams lm) {
   __shared__ double red[6 * 4];
@@ -216,12 +216,12 @@ __global__ __launch_bounds__(kBlock) void k_camera_rhs(DevP P, LmParams lm) {
   for (long long o = P.cm_start[g] + threadIdx.x; o < o1; o += kBlock) {
     const int pp = P.cm_dp[o];
     if (pp >= P.n_pm_points) continue;  // constant landmark: nothing was eliminated
-    const double* p = P.points[sel] + 3ll * pp;
+    const double* rec = P.prec + 16ll * pp;  // the landmark's record: p in words 0-2, scale_p o (V^-1 g_p) in 12-14
+    const double p[3] = {rec[0], rec[1], rec[2]};
     const double2 uv = reinterpret_cast<const double2*>(P.cm_uv)[o];
     double r[2], Jc[12], Jp[6];
-    eval_obs<true>(K, lm, pose, p, uv.x, uv.y, sc, nullptr, r, Jc, Jp);  // landmark columns unscaled: vg carries scale_p
-    const double* tg = P.vg + 3ll * pp;
-    const double t0 = tg[0], t1 = tg[1], t2 = tg[2];
+    eval_obs<true>(K, lm, pose, p, uv.x, uv.y, sc, nullptr, r, Jc, Jp);  // landmark columns unscaled: the record carries scale_p
+    const double t0 = rec[12], t1 = rec[13], t2 = rec[14];
     const double m0 = Jp[0] * t0 + Jp[1] * t1 + Jp[2] * t2;
     const double m1 = Jp[3] * t0 + Jp[4] * t1 + Jp[5] * t2;
 #pragma unroll
@@ -576,11 +576,6 @@ __global__ __launch_bounds__(kBlock) void k_point_schur(DevP P, LmParams lm, int
           const double gu = gpv[i] / sp;
           gmax = fmax(gmax, fabs(gu));
           g2 += gu * gu;
-          if (MODE == 2) {
-            // scale_p o (V^-1 g_p): what k_camera_rhs multiplies the unscaled landmark Jacobian with
-            const int r0 = i == 0 ? 0 : (i == 1 ? 1 : 2), r1 = i == 0 ? 1 : (i == 1 ? 3 : 4), r2 = i == 0 ? 2 : (i == 1 ? 4 : 5);
-            P.vg[3ll * pp + i] = sp * (Vi[r0] * gpv[0] + Vi[r1] * gpv[1] + Vi[r2] * gpv[2]);
-          }
         }
         if (MODE == 2) {
           double* rec = P.prec + 16ll * pp;
@@ -589,8 +584,11 @@ __global__ __launch_bounds__(kBlock) void k_point_schur(DevP P, LmParams lm, int
           for (int i = 0; i < 3; ++i) { rec[i] = p[i]; rec[3 + i] = P.scale_p[3ll * pp + i]; }
 #pragma unroll
           for (int i = 0; i < 6; ++i) rec[6 + i] = Vi[i];
-#pragma unroll
-          for (int i = 12; i < 16; ++i) rec[i] = 0.0;  // the whole line is staged through LDS by the gather: keep it finite
+          // scale_p o (V^-1 g_p) rides in the spare words: k_camera_rhs finds everything about a landmark in one line
+          rec[12] = P.scale_p[3ll * pp] * (Vi[0] * gpv[0] + Vi[1] * gpv[1] + Vi[2] * gpv[2]);
+          rec[13] = P.scale_p[3ll * pp + 1] * (Vi[1] * gpv[0] + Vi[3] * gpv[1] + Vi[4] * gpv[2]);
+          rec[14] = P.scale_p[3ll * pp + 2] * (Vi[2] * gpv[0] + Vi[4] * gpv[1] + Vi[5] * gpv[2]);
+          rec[15] = 0.0;  // the whole line is staged through LDS by the gather: keep it finite
         }
       }
       if (MODE != 2 && slot >= 0) {
@@ -729,7 +727,7 @@ __global__ __launch_bounds__(kBlock) void k_schur_gather(DevP P, LmParams lm) {
   double* S = P.S + P.wd[0].S_off;
   const bool robust = lm.loss != HIPBA_LOSS_NONE;
   const int e = lane < 36 ? lane : 0;
-  const long long q0 = P.chunk_start[chunk], q1 = P.chunk_start[chunk + 1];
+  const long long q0 = P.chunk_start[2 * chunk], q1 = P.chunk_start[2 * chunk + 1];
   // the pad column of every row and the words after the last row are read (and multiplied by zero) by the sums
   if (lane < 36) sT[lane * kGatherRow + 64] = 0.0;
   if (lane < 16) sT[36 * kGatherRow + lane] = 0.0;
