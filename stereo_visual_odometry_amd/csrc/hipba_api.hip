@@ -61,7 +61,8 @@ struct hipba_handle_s {
   size_t arena_bytes = 0;
   void* staging = nullptr;  // pinned host memory
   size_t staging_bytes = 0;
-  int* h_count = nullptr;   // pinned: windows still active
+  int* h_count = nullptr;   // pinned: windows still active, one word per slot of the poll ring
+  hipEvent_t poll_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // ring of "activity count copied" events
 };
 
 struct WinMeta {
@@ -460,6 +461,8 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
       const bool counting = n_dest_max <= (1ll << 22);
       if (counting) count.assign(n_dest_max, 0);
       std::vector<unsigned short> out;
+      runs_of[ti].reserve(pairs.size() / (n_thr * 2) + 16);
+      nruns_of[ti].reserve(b1 - b0);
       for (int bi = b0; bi < b1; ++bi) {
         const BlockDesc& d = blocks[bi];
         const int ncam = wd[d.window].ncam, cam_base = wd[d.window].cam_base;
@@ -470,11 +473,9 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
             ++nr;
           }
         };
-        auto dest_of_pair = [&](unsigned short pr) {
-          const int si = pose_gslot[obs_pose[d.obs_begin + (pr & 0xff)]] - cam_base;
-          const int sj = pose_gslot[obs_pose[d.obs_begin + (pr >> 8)]] - cam_base;
-          return tri_index(si, sj, ncam);
-        };
+        int lane_slot[kBlock];  // window slot of each observation of the block (looked up once, not per pair)
+        for (int i = 0; i < d.n_obs; ++i) lane_slot[i] = pose_gslot[obs_pose[d.obs_begin + i]] - cam_base;
+        auto dest_of_pair = [&](unsigned short pr) { return tri_index(lane_slot[pr & 0xff], lane_slot[pr >> 8], ncam); };
         if (counting) {
           key.resize(d.n_pairs);
           out.resize(d.n_pairs);
@@ -804,10 +805,20 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
       HIPBA_HIP(launch_window_control(P, lm, kFused, s));
     }
     iterations_run = iter;
-    HIPBA_HIP(launch_count_active(P, R->d_count, s));
-    HIPBA_HIP(hipMemcpyAsync(h->h_count, R->d_count, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPBA_HIP(hipStreamSynchronize(s));
-    if (*h->h_count == 0) break;
+    // "windows still active" travels to the host through a ring of pinned words.  Small windows: the host looks
+    // at the count of iteration iter - 2 before queueing iter + 1, so the queue never runs dry between
+    // iterations (every kernel returns at once for a window that has stopped; at most two idle iterations are
+    // queued).  Large windows and big batches poll every iteration: an idle pass there is not free.
+    const int slot = iter & 3;
+    HIPBA_HIP(launch_count_active(P, R->d_count + slot, s));
+    HIPBA_HIP(hipMemcpyAsync(h->h_count + slot, R->d_count + slot, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPBA_HIP(hipEventRecord(h->poll_ev[slot], s));
+    const int lag = (small && !sharded && P.n_windows <= 8) ? 2 : 0;
+    if (iter - lag >= 1) {
+      const int seen = (iter - lag) & 3;
+      HIPBA_HIP(hipEventSynchronize(h->poll_ev[seen]));
+      if (h->h_count[seen] == 0) break;
+    }
   }
 #undef AR
   (void)iterations_run;
@@ -955,6 +966,7 @@ int hipba_create(int device, hipba_handle* out) {
   h->device = device;
   e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_count, 64, hipHostMallocDefault);
+  for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&h->poll_ev[i], hipEventDisableTiming);
   if (e != hipSuccess) { delete h; return fail(HIPBA_ERR_HIP, "handle creation: %s", hipGetErrorString(e)); }
   *out = h;
   return HIPBA_OK;
@@ -967,6 +979,7 @@ int hipba_destroy(hipba_handle h) {
   if (h->arena) (void)hipFree(h->arena);
   if (h->staging) (void)hipHostFree(h->staging);
   if (h->h_count) (void)hipHostFree(h->h_count);
+  for (int i = 0; i < 4; ++i) if (h->poll_ev[i]) (void)hipEventDestroy(h->poll_ev[i]);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return HIPBA_OK;
