@@ -15,7 +15,8 @@ def main():
     dist.init_process_group("gloo")
     print("rank", rank, "up", flush=True)
     solver = hipba.Solver(0)
-    prob, _, _ = scenes.bal_scale(seed=5, grid=(8, 10), n_points=40000, depth_lo=5.0, depth_hi=30.0)
+    n_points = int(sys.argv[1]) if len(sys.argv) > 1 else 40000  # 160000: every rank in the gathered elimination mode
+    prob, _, _ = scenes.bal_scale(seed=5, grid=(8, 10), n_points=n_points, depth_lo=5.0, depth_hi=30.0)
     comm = TorchComm(torch.device("cuda", 0))
     job = ShardedProblem(solver, prob, comm)
     opts = hipba.default_options(max_num_iterations=5)

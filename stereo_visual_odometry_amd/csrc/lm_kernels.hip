@@ -1519,10 +1519,12 @@ __global__ __launch_bounds__(kBlock) void k_residual_jacobian(CameraK K, LmParam
       for (int i = 0; i < 12; ++i) sJ[13 * t + i] = Jc[i];
     }
     __syncthreads();
+    // pairs of doubles: 16 bytes per lane, streaming (the Jacobian is not read again by this kernel)
     double* dst = jac_pose + 12 * o0;
-    for (int idx = t; idx < 12 * nvalid; idx += kBlock) {
-      const int l = idx / 12;
-      dst[idx] = sJ[13 * l + (idx - 12 * l)];
+    for (int idx = t; idx < 6 * nvalid; idx += kBlock) {
+      const int l = idx / 6, k = 2 * (idx - 6 * l);
+      __builtin_nontemporal_store(sJ[13 * l + k], dst + 2 * idx);
+      __builtin_nontemporal_store(sJ[13 * l + k + 1], dst + 2 * idx + 1);
     }
     __syncthreads();
   }
@@ -1533,9 +1535,10 @@ __global__ __launch_bounds__(kBlock) void k_residual_jacobian(CameraK K, LmParam
     }
     __syncthreads();
     double* dst = jac_point + 6 * o0;
-    for (int idx = t; idx < 6 * nvalid; idx += kBlock) {
-      const int l = idx / 6;
-      dst[idx] = sJ[7 * l + (idx - 6 * l)];
+    for (int idx = t; idx < 3 * nvalid; idx += kBlock) {
+      const int l = idx / 3, k = 2 * (idx - 3 * l);
+      __builtin_nontemporal_store(sJ[7 * l + k], dst + 2 * idx);
+      __builtin_nontemporal_store(sJ[7 * l + k + 1], dst + 2 * idx + 1);
     }
   }
   block_sum<1>(c, red);

@@ -369,6 +369,31 @@ def test_staged_schur_accumulation_matches_oracle(solver, oracle, loss):
     assert np.abs(g.poses - g2.poses).max() <= 1e-11
 
 
+def test_gathered_elimination_with_constant_poses_and_landmarks(solver, oracle):
+    """The per-block gather next to every observation class: constant poses (their observations feed V and g_p but
+    no block of S), constant landmarks seen by variable poses (camera blocks only) and by constant poses (fixed
+    cost).  Ground-truth values for the constants, so the problem stays well posed."""
+    prob, gt_p, gt_q = scenes.bal_scale(seed=23, grid=(10, 10), n_points=70000, depth_lo=5.0, depth_hi=30.0)
+    rng = np.random.default_rng(7)
+    pose_const = np.zeros(prob.poses.shape[0], dtype=np.uint8)
+    pose_const[[0, 17, 18, 55, 99]] = 1
+    point_const = (rng.uniform(size=prob.points.shape[0]) < 0.1).astype(np.uint8)
+    prob.poses[pose_const == 1] = gt_p[pose_const == 1]
+    prob.points[point_const == 1] = gt_q[point_const == 1]
+    prob.pose_const, prob.point_const = pose_const, point_const
+    g = prob.copy()
+    s = solver.solve(g, hipba.default_options(max_num_iterations=5))
+    assert s["num_active_poses"] == 95 and s["fixed_cost"] > 0.0
+    o = to_oracle(oracle, prob)
+    so, oits = oracle.solve(o, oracle.default_options(max_num_iterations=5, jacobian_mode=oracle.JAC_ANALYTIC, num_threads=8))
+    assert s["termination_type"] == so["termination_type"]
+    assert abs(s["final_cost"] - so["final_cost"]) <= RTOL_COST * so["final_cost"]
+    assert np.abs(g.poses - o.poses).max() <= ATOL_STATE and np.abs(g.points - o.points).max() <= ATOL_STATE
+    assert_logs_match(s["iterations"], oits)
+    assert np.array_equal(g.poses[pose_const == 1], prob.poses[pose_const == 1])
+    assert np.array_equal(g.points[point_const == 1], prob.points[point_const == 1])
+
+
 def _check_against_oracle(oracle, prob, gpu_prob, summary, loss=None, loss_scale=1.0, max_iter=300):
     o = to_oracle(oracle, prob)
     kw = dict(max_num_iterations=max_iter, jacobian_mode=oracle.JAC_ANALYTIC, num_threads=8)
