@@ -450,8 +450,11 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   std::vector<RunDesc> runs;
   const long long n_dest_max = (long long)max_ncam * (max_ncam + 1) / 2;
   if (!staged && n_blk_pm > 0) {
+    // a keyframe window has ~10^5 pairs: worth four short-lived threads (grouping them is the longest host step
+    // of hipba_solve); large problems use up to sixteen
     const int n_thr = (int)std::min<size_t>(std::max(1u, std::min(16u, std::thread::hardware_concurrency())),
-                                            1 + pairs.size() / 1000000);
+                                            pairs.size() < 1000000 ? std::min<size_t>(4, 1 + pairs.size() / 20000)
+                                                                   : 1 + pairs.size() / 1000000);
     std::vector<std::vector<RunDesc>> runs_of(n_thr);
     std::vector<std::vector<int>> nruns_of(n_thr);
     auto group_range = [&](int ti, int b0, int b1) {
