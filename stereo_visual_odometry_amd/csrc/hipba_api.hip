@@ -785,12 +785,12 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
       HIPBA_HIP(launch_window_gradient(P, lm, kDecide, s));
     }
     if (small && !sharded) {
-      HIPBA_HIP(launch_window_solve_small(P, lm, max_n, s));
+      HIPBA_HIP(launch_window_solve_small(P, lm, max_n, 1, s));  // also forms the candidate poses
     } else {
       if (!sharded) HIPBA_HIP(launch_window_gradient(P, lm, kFused, s));
       if (small) {
         // sharded small window: gradient already decided; the LDS solver repeats the (idempotent) check
-        HIPBA_HIP(launch_window_solve_small(P, lm, max_n, s));
+        HIPBA_HIP(launch_window_solve_small(P, lm, max_n, 0, s));
       } else if (solver == HIPBA_LINEAR_PCG) {
         HIPBA_HIP(big_solve_pcg(P, R->big, o.pcg_max_iterations, o.pcg_tolerance, s));
       } else {
@@ -798,14 +798,15 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
       }
     }
     HIPBA_HIP(launch_backsub(P, lm, s));
-    HIPBA_HIP(launch_pose_update(P, s));
+    if (!(small && !sharded)) HIPBA_HIP(launch_pose_update(P, s));
     HIPBA_HIP(launch_cost(P, lm, 0, n_act_blk, 1, 0, true, s));
     if (sharded) {
-      HIPBA_HIP(launch_window_control(P, lm, kReduce, s));
+      HIPBA_HIP(launch_window_control(P, lm, kReduce, nullptr, s));
       AR(P.wsum, 5, HIPBA_REDUCE_SUM);
-      HIPBA_HIP(launch_window_control(P, lm, kDecide, s));
+      HIPBA_HIP(launch_window_control(P, lm, kDecide, nullptr, s));
     } else {
-      HIPBA_HIP(launch_window_control(P, lm, kFused, s));
+      // a single window reports "still active" itself; batches are counted by k_count_active below
+      HIPBA_HIP(launch_window_control(P, lm, kFused, P.n_windows == 1 ? R->d_count + (iter & 3) : nullptr, s));
     }
     iterations_run = iter;
     // "windows still active" travels to the host through a ring of pinned words.  Small windows: the host looks
@@ -813,7 +814,7 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
     // iterations (every kernel returns at once for a window that has stopped; at most two idle iterations are
     // queued).  Large windows and big batches poll every iteration: an idle pass there is not free.
     const int slot = iter & 3;
-    HIPBA_HIP(launch_count_active(P, R->d_count + slot, s));
+    if (sharded || P.n_windows != 1) HIPBA_HIP(launch_count_active(P, R->d_count + slot, s));
     HIPBA_HIP(hipMemcpyAsync(h->h_count + slot, R->d_count + slot, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPBA_HIP(hipEventRecord(h->poll_ev[slot], s));
     const int lag = (small && !sharded && P.n_windows <= 8) ? 2 : 0;
@@ -1191,7 +1192,7 @@ int hipba_time_kernel(hipba_handle h, hipba_device_problem dp, const hipba_optio
     return HIPBA_OK;
   };
   auto solve_once = [&]() -> int {
-    if (small) HIPBA_HIP(launch_window_solve_small(P, lm, max_n, s));
+    if (small) HIPBA_HIP(launch_window_solve_small(P, lm, max_n, 0, s));
     else if (o.linear_solver == HIPBA_LINEAR_PCG) HIPBA_HIP(big_solve_pcg(P, dp->big, o.pcg_max_iterations, o.pcg_tolerance, s));
     else HIPBA_HIP(big_solve_cholesky(P, dp->big, s));
     return HIPBA_OK;

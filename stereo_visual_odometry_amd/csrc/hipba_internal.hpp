@@ -18,12 +18,12 @@ hipError_t launch_make_scale_c(const DevP& P, int jacobi, hipStream_t s);
 hipError_t launch_point_colnorm(const DevP& P, const LmParams& lm, hipStream_t s);
 hipError_t launch_init_reduced(const DevP& P, const LmParams& lm, int owner, hipStream_t s);
 hipError_t launch_point_schur(const DevP& P, const LmParams& lm, int small_ncam, int parts, hipStream_t s);
-hipError_t launch_window_solve_small(const DevP& P, const LmParams& lm, int max_n, hipStream_t s);
+hipError_t launch_window_solve_small(const DevP& P, const LmParams& lm, int max_n, int fuse_pose_update, hipStream_t s);
 hipError_t launch_window_gradient(const DevP& P, const LmParams& lm, int mode, hipStream_t s);
 hipError_t launch_backsub(const DevP& P, const LmParams& lm, hipStream_t s);
 hipError_t launch_pose_update(const DevP& P, hipStream_t s);
 hipError_t launch_window_init(const DevP& P, const LmParams& lm, int mode, hipStream_t s);
-hipError_t launch_window_control(const DevP& P, const LmParams& lm, int mode, hipStream_t s);
+hipError_t launch_window_control(const DevP& P, const LmParams& lm, int mode, int* count_out, hipStream_t s);
 hipError_t launch_count_active(const DevP& P, int* out, hipStream_t s);
 hipError_t launch_residual_jacobian(const CameraK& K, const LmParams& lm, int apply_loss, long long n_obs,
                                     const double* poses, const double* points, const int* obs_pose,

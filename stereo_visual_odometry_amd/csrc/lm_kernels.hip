@@ -956,15 +956,14 @@ __global__ __launch_bounds__(kBlock) void k_backsub(DevP P, LmParams lm) {
 
 // candidate poses T * exp(delta_c) (Sophus::Manifold<SE3>::Plus) and their norm terms,
 // one workgroup per window
-__global__ __launch_bounds__(kBlock) void k_pose_update(DevP P) {
-  __shared__ double red[2 * 4];
-  const int w = blockIdx.x;
+// candidate poses x+ = x * exp(-y_c o scale_c) of window w and the pose part of |x+ - x|^2, |x|^2, by the calling
+// workgroup (any size that is a multiple of 64; red: two words per wave)
+__device__ __forceinline__ void pose_update_window(const DevP& P, int w, double* red) {
   WinState* st = P.ws + w;
-  if (!st->active || st->solve_failed) return;
   const WinDesc wd = P.wd[w];
   const int sel = st->sel;
   double acc[2] = {0.0, 0.0};
-  for (int c = wd.pose_begin + threadIdx.x; c < wd.pose_end; c += kBlock) {
+  for (int c = wd.pose_begin + threadIdx.x; c < wd.pose_end; c += blockDim.x) {
     const int g = P.pose_gslot[c];
     if (g < 0) continue;
     double x[7], dl[6], xn[7];
@@ -983,6 +982,13 @@ __global__ __launch_bounds__(kBlock) void k_pose_update(DevP P) {
   }
   block_sum<2>(acc, red);
   if (threadIdx.x == 0) { st->pose_step2 = acc[0]; st->pose_x2 = acc[1]; }
+}
+
+__global__ __launch_bounds__(kBlock) void k_pose_update(DevP P) {
+  __shared__ double red[2 * 4];
+  const WinState* st = P.ws + blockIdx.x;
+  if (!st->active || st->solve_failed) return;
+  pose_update_window(P, blockIdx.x, red);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1109,7 +1115,7 @@ __device__ void window_gradient_check(const DevP& P, const LmParams& lm, const W
 
 // end of an iteration: reduce the per-block partials and run Ceres' acceptance logic
 // (TrustRegionMinimizer::Minimize, LevenbergMarquardtStrategy::StepAccepted/Rejected/IsInvalid)
-__global__ __launch_bounds__(kBlock) void k_window_control(DevP P, LmParams lm, int mode) {
+__device__ __forceinline__ void window_control_body(const DevP& P, const LmParams& lm, int mode) {
   __shared__ double red[5 * 4];
   const int w = blockIdx.x;
   WinState* st = P.ws + w;
@@ -1218,6 +1224,13 @@ __global__ __launch_bounds__(kBlock) void k_window_control(DevP P, LmParams lm, 
   *st = s;
 }
 
+// count_out (one-window solves): the "windows still active" word the host polls, written here instead of by a
+// launch of k_count_active
+__global__ __launch_bounds__(kBlock) void k_window_control(DevP P, LmParams lm, int mode, int* count_out) {
+  window_control_body(P, lm, mode);
+  if (count_out && threadIdx.x == 0) *count_out = P.ws[blockIdx.x].active ? 1 : 0;
+}
+
 // ------------------------------------------------------------------------------------------
 // reduced solve for small windows: gradient check, then Cholesky of the packed S in LDS
 // (one workgroup per window, n = 6 * ncam <= kSmallMaxN)
@@ -1285,7 +1298,9 @@ __device__ __forceinline__ bool factor_invert_6x6(double* D) {
   return ok;
 }
 
-__global__ __launch_bounds__(kSolveThreads) void k_window_solve_small(DevP P, LmParams lm) {
+// fuse_pose_update: the workgroup goes on to form the window's candidate poses (k_pose_update's work) from the
+// solution it has just written: one launch less per iteration.
+__global__ __launch_bounds__(kSolveThreads) void k_window_solve_small(DevP P, LmParams lm, int fuse_pose_update) {
   // all LDS comes from the dynamic region so that its base stays 16-byte aligned
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* red = smem;                                  // [8]
@@ -1471,8 +1486,15 @@ __global__ __launch_bounds__(kSolveThreads) void k_window_solve_small(DevP P, Lm
   HIPBA_TICK(4);
   if (t < 64) {
     const unsigned long long okm = __ballot(ok);
-    if (t == 0 && okm != ~0ull) st->solve_failed = 1;
+    if (t == 0) {
+      fail = okm != ~0ull;
+      if (fail) st->solve_failed = 1;
+    }
   }
+  if (!fuse_pose_update) return;
+  __syncthreads();  // the solution (global) and the verdict (LDS) are visible to the whole workgroup
+  if (fail) return;
+  pose_update_window(P, w, Rm);  // the matrix words are free: two sums per wave go there
 }
 #undef HIPBA_UIDX
 
@@ -1653,7 +1675,7 @@ hipError_t launch_point_schur(const DevP& P, const LmParams& lm, int small_ncam,
   return hipGetLastError();
 }
 
-hipError_t launch_window_solve_small(const DevP& P, const LmParams& lm, int max_n, hipStream_t s) {
+hipError_t launch_window_solve_small(const DevP& P, const LmParams& lm, int max_n, int fuse_pose_update, hipStream_t s) {
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_window_solve_small),
@@ -1662,7 +1684,7 @@ hipError_t launch_window_solve_small(const DevP& P, const LmParams& lm, int max_
   }
   const size_t nb = (size_t)(max_n + 5) / 6;
   const size_t lds = (16 + nb * (nb + 1) / 2 * kSmallBlk + 6 * nb) * 8;
-  hipLaunchKernelGGL(k_window_solve_small, dim3(P.n_windows), dim3(kSolveThreads), lds, s, P, lm);
+  hipLaunchKernelGGL(k_window_solve_small, dim3(P.n_windows), dim3(kSolveThreads), lds, s, P, lm, fuse_pose_update);
   return hipGetLastError();
 }
 
@@ -1688,8 +1710,8 @@ hipError_t launch_window_init(const DevP& P, const LmParams& lm, int mode, hipSt
   return hipGetLastError();
 }
 
-hipError_t launch_window_control(const DevP& P, const LmParams& lm, int mode, hipStream_t s) {
-  hipLaunchKernelGGL(k_window_control, dim3(P.n_windows), dim3(kBlock), 0, s, P, lm, mode);
+hipError_t launch_window_control(const DevP& P, const LmParams& lm, int mode, int* count_out, hipStream_t s) {
+  hipLaunchKernelGGL(k_window_control, dim3(P.n_windows), dim3(kBlock), 0, s, P, lm, mode, count_out);
   return hipGetLastError();
 }
 
