@@ -5,6 +5,14 @@ import sys
 import numpy as np
 import pytest
 
+# torch first: its wheel carries its own copy of the HIP runtime, and a process that has already initialised the
+# system copy through libhipba.so may find torch unable to see the GPU afterwards (the tests that need both are
+# the collective ones)
+try:
+    import torch  # noqa: F401
+except ImportError:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

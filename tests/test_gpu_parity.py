@@ -442,3 +442,36 @@ def test_long_tracks_pair_lists_beyond_the_lds_stage(solver, oracle, n_frames):
     g = prob.copy()
     s = solver.solve(g, hipba.default_options(max_num_iterations=30))
     _check_against_oracle(oracle, prob, g, s, max_iter=30)
+
+
+def test_rccl_all_reduce_on_the_engine_stream_single_rank():
+    """The collective path of a sharded solve on a real GPU, as far as one GPU allows: an RCCL ("nccl") process
+    group of one rank, TorchComm's callback called the way the engine calls it -- fp64 SUM and MAX on a device
+    buffer, issued on the engine's own stream through torch.cuda.ExternalStream.  (Two ranks cannot share a GPU
+    under RCCL; the two-rank logic is covered by the threaded test above and the gloo test.)"""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from stereo_visual_odometry_amd.sharded import TorchComm
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    if not torch.cuda.is_available():
+        pytest.skip("torch does not see the GPU in this process (its HIP runtime was not the first one loaded)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        sv = hipba.Solver(0)
+        comm = TorchComm(torch.device("cuda", 0))
+        buf = torch.arange(1000, dtype=torch.float64, device="cuda") - 300.0
+        want = buf.clone()
+        torch.cuda.synchronize()
+        for op in (hipba.REDUCE_SUM, hipba.REDUCE_MAX):
+            assert comm._allreduce(None, buf.data_ptr(), buf.numel(), op, sv.stream) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(buf, want) and comm.calls == 2 and comm.bytes == 16000
+        sv.close()
+    finally:
+        dist.destroy_process_group()
