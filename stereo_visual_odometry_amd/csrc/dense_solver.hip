@@ -146,7 +146,7 @@ constexpr size_t kPotrfLds = (size_t)(NTL * (NTL + 1) / 2) * kTile * 8 + 64 + NB
 // UPD: the block is first brought up to date with panel columns [kcol0, kcol0 + K) of its own block row,
 //   A(k,k) -= L(k, cols) L(k, cols)^T, 64 columns per stage through LDS (the tile area doubles as the stage),
 //   so that the workgroup can run beside the kernel that applies the same update to the rest of the matrix.
-template <bool UPD, int PH = 0xff>
+template <bool UPD>
 __device__ __forceinline__ void potrf_block(const DevP& P, double* A, int ld, int k, double* Linv_all, double* LinvT_all,
                                             double* smem, int kcol0, int K) {
   double* Lt = smem;                                   // 36 tiles; the diagonal ones hold their inverses at the end
@@ -242,14 +242,14 @@ __device__ __forceinline__ void potrf_block(const DevP& P, double* A, int ld, in
       }
     }
   };
-  if (wave == 0 && (PH & 1)) diag_tile(0);
+  if (wave == 0) diag_tile(0);
   __syncthreads();
   for (int j = 0; j < NTL; ++j) {
     if (j == 2) HIPBA_CYCLES(5);
     if (fail) break;
     // (b) panel below the diagonal tile: L(i,j) = A(i,j) L(j,j)^-T, one lane per row, forward substitution with
     // the diagonal tile read from LDS (every lane reads the same words: broadcasts)
-    if (t < TB * (NTL - 1 - j) && (PH & 2)) {
+    if (t < TB * (NTL - 1 - j)) {
       double* T = Lt + ltile(j + 1 + (t >> 4), j) + (t & 15);
       const double* D = Lt + ltile(j, j);
       const double* ri = rdiag + j * TB;
@@ -273,7 +273,7 @@ __device__ __forceinline__ void potrf_block(const DevP& P, double* A, int ld, in
     // the next diagonal tile alone and factors it at once (the longest single-wave job of a step) while the
     // other three waves share the remaining tiles.
     if (wave == 0) {
-      if (j + 1 < NTL && (PH & 4)) {
+      if (j + 1 < NTL) {
         double* C = Lt + ltile(j + 1, j + 1);
         v4d acc = tile_load_t(C, lane);
         acc = mfma_tile<true>(Lt + ltile(j + 1, j), Lt + ltile(j + 1, j), acc, lane);
@@ -281,11 +281,11 @@ __device__ __forceinline__ void potrf_block(const DevP& P, double* A, int ld, in
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (PH & 1) diag_tile(j + 1);
+        diag_tile(j + 1);
       }
     } else {
       int e = 0;
-      for (int i2 = j + 2; i2 < NTL && (PH & 4); ++i2) {
+      for (int i2 = j + 2; i2 < NTL; ++i2) {
         for (int j2 = j + 1; j2 <= i2; ++j2, ++e) {
           if (e % 3 != wave - 1) continue;
           double* C = Lt + ltile(i2, j2);
@@ -343,7 +343,7 @@ __device__ __forceinline__ void potrf_block(const DevP& P, double* A, int ld, in
   // without a trip through LDS.
   double* Linv = Linv_all + (long long)k * NB * NB;
   double* LinvT = LinvT_all + (long long)k * NB * NB;
-  for (int pass = 0; pass < 2 && (PH & 8); ++pass) {
+  for (int pass = 0; pass < 2; ++pass) {
     const int j = pass == 0 ? wave : NTL - 1 - wave;
     // tiles above the diagonal are zero
     for (int i = 0; i < j; ++i) {
@@ -388,12 +388,11 @@ __device__ __forceinline__ void potrf_block(const DevP& P, double* A, int ld, in
   HIPBA_CYCLES(4);
 }
 
-template <int PH = 0xff>
 __global__ __launch_bounds__(256) void k_potrf_inv(DevP P, double* A, int ld, int k, double* Linv_all,
                                                    double* LinvT_all) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   if (!P.ws[0].active || P.ws[0].solve_failed) return;
-  potrf_block<false, PH>(P, A, ld, k, Linv_all, LinvT_all, smem, 0, 0);
+  potrf_block<false>(P, A, ld, k, Linv_all, LinvT_all, smem, 0, 0);
 }
 
 // ---- fp64 matrix-core GEMM, C(i,j) (op)= sum_k A(i,k) B(j,k), column-major, 128x128 tiles ----------
@@ -755,7 +754,7 @@ hipError_t big_solve_cholesky(const DevP& P, const BigWork& W, hipStream_t s) {
   constexpr size_t kLdsNtFused = kGemmNtLds > kPotrfLds ? kGemmNtLds : kPotrfLds;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_potrf_inv<0xff>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_potrf_inv), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)kPotrfLds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_k128<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)kLdsK128Fused);
@@ -781,7 +780,7 @@ hipError_t big_solve_cholesky(const DevP& P, const BigWork& W, hipStream_t s) {
   // Block size: with the panel factorisations hidden in the narrow updates, wide blocks win -- measured at 94
   // panels: 8 -> 18.8 ms, 16 -> 17.7, 24 -> 17.7, 32 -> 17.0, 47 -> 19.3 (30 and 34-40: 18.3-19.1).
   const int kOuter = nt >= 64 ? 32 : (nt >= 24 ? 16 : 8);
-  hipLaunchKernelGGL(k_potrf_inv<0xff>, dim3(1), dim3(256), kPotrfLds, s, P, W.A, ld, 0, W.Linv, W.LinvT);
+  hipLaunchKernelGGL(k_potrf_inv, dim3(1), dim3(256), kPotrfLds, s, P, W.A, ld, 0, W.Linv, W.LinvT);
   for (int p0 = 0; p0 < nt; p0 += kOuter) {
     const int p1 = p0 + kOuter < nt ? p0 + kOuter : nt;
     for (int p = p0; p < p1; ++p) {
