@@ -1379,6 +1379,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_window_solve_small(DevP P, Lm
     const int nitem = 2 * npair + m;
     if (t == 0) {
       if (m > 0) {
+        __builtin_amdgcn_s_setprio(3);  // the chain below is the critical path of the step: issue it first
         const double* Ri = Rm + (rowk + 1) * kSmallBlk;
         double* T = Rm + (int)tri_index(k + 1, k + 1, nb) * kSmallBlk;
         double ri[36];
@@ -1395,9 +1396,11 @@ __global__ __launch_bounds__(kSolveThreads) void k_window_solve_small(DevP P, Lm
           }
         }
         if (!factor_invert_6x6(T)) fail = 1;
+        __builtin_amdgcn_s_setprio(0);
       }
-    } else {
-      for (int e = 1 + t; e < nitem; e += kSolveThreads - 1) {
+    } else if (t >= 64) {
+      // (the rest of wave 0 idles: it would run this loop after lane 0's chain, not beside it)
+      for (int e = 2 + (t - 64); e < nitem; e += kSolveThreads - 64) {
         if (e < 2 * npair) {
           const int p = e >> 1, h = e & 1;
           // row ii of an m-row upper triangle starts at ii*m - ii(ii-1)/2
