@@ -1460,6 +1460,9 @@ __global__ __launch_bounds__(kSolveThreads) void k_window_solve_small(DevP P, Lm
   // lane per row above subtracts that block column's contribution
   bool ok = true;
   for (int k = nb - 1; k >= 0; --k) {
+    // only the waves that have a row to update (or the six lanes that store y) form y: the others would
+    // just take issue slots from them
+    if ((t & ~63) < (6 * k > 6 ? 6 * k : 6)) {
     const double* X = Rm + (int)tri_index(k, k, nb) * kSmallBlk;
     double zk[6], y[6];
 #pragma unroll
@@ -1483,6 +1486,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_window_solve_small(DevP P, Lm
 #pragma unroll
       for (int c = 0; c < 6; ++c) v -= B[c] * y[c];
       zb[e] = v;
+    }
     }
     __syncthreads();
   }
