@@ -762,19 +762,21 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
   } else {
     HIPBA_HIP(launch_window_init(P, lm, kFused, s));
   }
-  HIPBA_HIP(launch_camera_blocks(P, lm, 0, s));
+  HIPBA_HIP(launch_camera_blocks(P, lm, 0, 0, s));
   if (sharded && P.n_act_poses) { AR(P.U, 36 * (size_t)P.n_act_poses, HIPBA_REDUCE_SUM); AR(P.gc, 6 * (size_t)P.n_act_poses, HIPBA_REDUCE_SUM); }
   HIPBA_HIP(launch_make_scale_c(P, lm.jacobi_scaling, s));
   HIPBA_HIP(launch_point_colnorm(P, lm, s));
 
   int iterations_run = 0;
   for (int iter = 1; iter <= std::max(lm.max_num_iterations, 0); ++iter) {
+    // S is zeroed first so that, unsharded, the camera-block launch can initialise the reduced system too
+    if (R->S_doubles) HIPBA_HIP(hipMemsetAsync(P.S, 0, sizeof(double) * (size_t)R->S_doubles, s));
+    const bool fuse_init = iter > 1 && !sharded;
     if (iter > 1) {
-      HIPBA_HIP(launch_camera_blocks(P, lm, 1, s));
+      HIPBA_HIP(launch_camera_blocks(P, lm, 1, fuse_init ? 1 : 0, s));
       if (sharded && P.n_act_poses) { AR(P.U, 36 * (size_t)P.n_act_poses, HIPBA_REDUCE_SUM); AR(P.gc, 6 * (size_t)P.n_act_poses, HIPBA_REDUCE_SUM); }
     }
-    if (R->S_doubles) HIPBA_HIP(hipMemsetAsync(P.S, 0, sizeof(double) * (size_t)R->S_doubles, s));
-    HIPBA_HIP(launch_init_reduced(P, lm, owner, s));
+    if (!fuse_init) HIPBA_HIP(launch_init_reduced(P, lm, owner, s));
     HIPBA_HIP(launch_point_schur(P, lm, small_ncam, schur_parts, s));
     if (sharded) {
       if (R->S_doubles) AR(P.S, (size_t)R->S_doubles, HIPBA_REDUCE_SUM);
@@ -1183,7 +1185,7 @@ int hipba_time_kernel(hipba_handle h, hipba_device_problem dp, const hipba_optio
     HIPBA_HIP(launch_cost(P, lm, 0, n_act_blk, 0, 1, false, s));
     HIPBA_HIP(launch_cost(P, lm, n_act_blk, P.n_blk_cc, 0, 1, false, s));
     HIPBA_HIP(launch_window_init(P, lm, kFused, s));
-    HIPBA_HIP(launch_camera_blocks(P, lm, 0, s));
+    HIPBA_HIP(launch_camera_blocks(P, lm, 0, 0, s));
     HIPBA_HIP(launch_make_scale_c(P, lm.jacobi_scaling, s));
     HIPBA_HIP(launch_point_colnorm(P, lm, s));
     if (dp->S_doubles) HIPBA_HIP(hipMemsetAsync(P.S, 0, sizeof(double) * (size_t)dp->S_doubles, s));
@@ -1222,7 +1224,7 @@ int hipba_time_kernel(hipba_handle h, hipba_device_problem dp, const hipba_optio
         HIPBA_HIP(launch_residual_jacobian(wd0.K, lm, 1, nj, P.poses[st0.sel], P.points[st0.sel], P.obs_pose, P.obs_dp,
                                            P.obs_uv, jbuf, jbuf + 2 * nj, jbuf + 14 * nj, nullptr, nullptr, s));
         break;
-      case HIPBA_KERNEL_CAMERA_BLOCKS: HIPBA_HIP(launch_camera_blocks(P, lm, 1, s)); break;
+      case HIPBA_KERNEL_CAMERA_BLOCKS: HIPBA_HIP(launch_camera_blocks(P, lm, 1, 0, s)); break;
       case HIPBA_KERNEL_POINT_SCHUR: HIPBA_HIP(launch_point_schur(P, lm, small_ncam, schur_parts, s)); break;
       case HIPBA_KERNEL_BACKSUB: HIPBA_HIP(launch_backsub(P, lm, s)); break;
       case HIPBA_KERNEL_REDUCED_SOLVE: return solve_once();

@@ -13,7 +13,7 @@ namespace hipba {
 size_t schur_lds_bytes(int small_ncam, bool staged);
 hipError_t launch_cost(const DevP& P, const LmParams& lm, int blk_off, int n_blk, int which, int ignore_active,
                        bool second_bank, hipStream_t s);
-hipError_t launch_camera_blocks(const DevP& P, const LmParams& lm, int use_scale, hipStream_t s);
+hipError_t launch_camera_blocks(const DevP& P, const LmParams& lm, int use_scale, int fuse_init, hipStream_t s);
 hipError_t launch_make_scale_c(const DevP& P, int jacobi, hipStream_t s);
 hipError_t launch_point_colnorm(const DevP& P, const LmParams& lm, hipStream_t s);
 hipError_t launch_init_reduced(const DevP& P, const LmParams& lm, int owner, hipStream_t s);

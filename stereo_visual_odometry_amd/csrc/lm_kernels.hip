@@ -143,10 +143,82 @@ __global__ __launch_bounds__(kBlock) void k_cost(DevP P, LmParams lm, int blk_of
 }
 
 // ------------------------------------------------------------------------------------------
+// reduced system initialisation, one thread per variable pose:
+//   S(c,c) = U_c + D_c^2,  b_c = g_c,  and the pose part of |x - Plus(x, -g)|.
+// S must have been zeroed on the stream before this kernel.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void init_reduced_pose(const DevP& P, const LmParams& lm, int g, int owner) {
+  const int c = P.slot_pose[g];
+  const int w = P.pose_window[c];
+  WinState* st = P.ws + w;
+  if (!st->active) return;
+  const WinDesc wd = P.wd[w];
+  const int slot = g - wd.cam_base;
+  double* Sb = P.S + wd.S_off + 36ll * tri_index(slot, slot, wd.ncam);
+  const double* U = P.U + 36ll * g;
+  const double inv_radius = 1.0 / st->radius;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      double v = U[6 * i + j];
+      if (i == j) {
+        double dg = fmin(fmax(v, lm.min_lm_diagonal), lm.max_lm_diagonal);
+        v += dg * inv_radius;
+      }
+      if (owner) Sb[6 * i + j] = v;  // sharded solves: one rank contributes U + D^2 and g_c
+    }
+  }
+  double neg[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const double gs = P.gc[6ll * g + i];
+    P.b[6ll * g + i] = owner ? gs : 0.0;
+    neg[i] = -gs / P.scale_c[6ll * g + i];
+  }
+  // gradient norms are defined through the retraction: |x - Plus(x, -g)|
+  const double* x = P.poses[st->sel] + 7ll * c;
+  double xp[7], xx[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) xx[i] = x[i];
+  se3_plus(xx, neg, xp);
+  double m = 0.0, s2 = 0.0;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const double dlt = xx[i] - xp[i];
+    m = fmax(m, fabs(dlt));
+    s2 += dlt * dlt;
+  }
+  // stash per pose in yc (overwritten by the solver afterwards): [0]=max, [1]=sum of squares
+  P.yc[6ll * g + 0] = m;
+  P.yc[6ll * g + 1] = s2;
+  if (P.cam_tab) {
+    // what k_schur_gather needs of a pose, once per iteration instead of once per product
+    double* ct = P.cam_tab + 18ll * g;
+    double Rt[9];
+    quat_to_Rt(xx, Rt);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) ct[i] = Rt[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) ct[9 + i] = Rt[3 * i] * xx[4] + Rt[3 * i + 1] * xx[5] + Rt[3 * i + 2] * xx[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) ct[12 + i] = P.scale_c[6ll * g + i];
+  }
+}
+
+__global__ void k_init_reduced(DevP P, LmParams lm, int owner) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= P.n_act_poses) return;
+  init_reduced_pose(P, lm, g, owner);
+}
+
+// ------------------------------------------------------------------------------------------
 // camera blocks: U_c = sum Jc^T Jc (6x6), g_c = sum Jc^T r over the camera's observations,
 // one workgroup per variable pose, walking its camera-major observation list.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_camera_blocks(DevP P, LmParams lm, int use_scale) {
+// fuse_init: thread 0 goes on to do k_init_reduced's work for this pose (S must have been zeroed before this
+// launch then): one launch less per iteration.
+__global__ __launch_bounds__(kBlock) void k_camera_blocks(DevP P, LmParams lm, int use_scale, int fuse_init) {
   __shared__ double red[27 * 4];
   const int g = blockIdx.x;
   const int c = P.slot_pose[g];
@@ -190,6 +262,7 @@ __global__ __launch_bounds__(kBlock) void k_camera_blocks(DevP P, LmParams lm, i
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) P.gc[6ll * g + i] = acc[21 + i];
+    if (fuse_init) init_reduced_pose(P, lm, g, 1);
   }
 }
 
@@ -291,71 +364,6 @@ __global__ __launch_bounds__(kBlock) void k_point_colnorm(DevP P, LmParams lm) {
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// reduced system initialisation, one thread per variable pose:
-//   S(c,c) = U_c + D_c^2,  b_c = g_c,  and the pose part of |x - Plus(x, -g)|.
-// S must have been zeroed on the stream before this kernel.
-// ------------------------------------------------------------------------------------------
-__global__ void k_init_reduced(DevP P, LmParams lm, int owner) {
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= P.n_act_poses) return;
-  const int c = P.slot_pose[g];
-  const int w = P.pose_window[c];
-  WinState* st = P.ws + w;
-  if (!st->active) return;
-  const WinDesc wd = P.wd[w];
-  const int slot = g - wd.cam_base;
-  double* Sb = P.S + wd.S_off + 36ll * tri_index(slot, slot, wd.ncam);
-  const double* U = P.U + 36ll * g;
-  const double inv_radius = 1.0 / st->radius;
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      double v = U[6 * i + j];
-      if (i == j) {
-        double dg = fmin(fmax(v, lm.min_lm_diagonal), lm.max_lm_diagonal);
-        v += dg * inv_radius;
-      }
-      if (owner) Sb[6 * i + j] = v;  // sharded solves: one rank contributes U + D^2 and g_c
-    }
-  }
-  double neg[6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    const double gs = P.gc[6ll * g + i];
-    P.b[6ll * g + i] = owner ? gs : 0.0;
-    neg[i] = -gs / P.scale_c[6ll * g + i];
-  }
-  // gradient norms are defined through the retraction: |x - Plus(x, -g)|
-  const double* x = P.poses[st->sel] + 7ll * c;
-  double xp[7], xx[7];
-#pragma unroll
-  for (int i = 0; i < 7; ++i) xx[i] = x[i];
-  se3_plus(xx, neg, xp);
-  double m = 0.0, s2 = 0.0;
-#pragma unroll
-  for (int i = 0; i < 7; ++i) {
-    const double dlt = xx[i] - xp[i];
-    m = fmax(m, fabs(dlt));
-    s2 += dlt * dlt;
-  }
-  // stash per pose in yc (overwritten by the solver afterwards): [0]=max, [1]=sum of squares
-  P.yc[6ll * g + 0] = m;
-  P.yc[6ll * g + 1] = s2;
-  if (P.cam_tab) {
-    // what k_schur_gather needs of a pose, once per iteration instead of once per product
-    double* ct = P.cam_tab + 18ll * g;
-    double Rt[9];
-    quat_to_Rt(xx, Rt);
-#pragma unroll
-    for (int i = 0; i < 9; ++i) ct[i] = Rt[i];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) ct[9 + i] = Rt[3 * i] * xx[4] + Rt[3 * i + 1] * xx[5] + Rt[3 * i + 2] * xx[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) ct[12 + i] = P.scale_c[6ll * g + i];
-  }
-}
 
 // ------------------------------------------------------------------------------------------
 // landmark elimination (k_schur_point + k_schur_camera of the design):
@@ -1618,9 +1626,9 @@ hipError_t launch_cost(const DevP& P, const LmParams& lm, int blk_off, int n_blk
   return hipGetLastError();
 }
 
-hipError_t launch_camera_blocks(const DevP& P, const LmParams& lm, int use_scale, hipStream_t s) {
+hipError_t launch_camera_blocks(const DevP& P, const LmParams& lm, int use_scale, int fuse_init, hipStream_t s) {
   if (P.n_act_poses <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_camera_blocks, dim3(P.n_act_poses), dim3(kBlock), 0, s, P, lm, use_scale);
+  hipLaunchKernelGGL(k_camera_blocks, dim3(P.n_act_poses), dim3(kBlock), 0, s, P, lm, use_scale, fuse_init);
   return hipGetLastError();
 }
 
