@@ -538,7 +538,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 constexpr int kTrsmRows = 32;  // rows per workgroup of the panel solve: 32 -> twice the workgroups of 64, all stages in flight
 template <int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm_k128(DevP P, double* Amat, int ld, int i0, int j0, int kcol,
-                                                     const double* Linv, double* fuse_linv, double* fuse_linvt) {
+                                                     const double* Linv, double* fuse_linv, double* fuse_linvt,
+                                                     int row_tiles) {
   constexpr int TI = MODE == 0 ? 64 : kTrsmRows, TJ = MODE == 0 ? 64 : NB;
   constexpr int LDA = TI + 16, LDB = TJ + 16;
   constexpr int PA = TI / 16, PB = TJ / 16;    // doubles per thread and stage
@@ -548,6 +549,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double (*sA)[KC * LDA] = reinterpret_cast<double (*)[KC * LDA]>(smem);
   double (*sB)[KC * LDB] = reinterpret_cast<double (*)[KC * LDB]>(smem + 2 * KC * LDA);
+  if ((int)blockIdx.x >= row_tiles) return;  // padding of the grid width
   if (MODE == 0 && fuse_linv && blockIdx.x < 2 && blockIdx.y < 2) {
     if (blockIdx.x == 0 && blockIdx.y == 0 && P.ws[0].active && !P.ws[0].solve_failed)
       potrf_block<true>(P, Amat, ld, i0, fuse_linv, fuse_linvt, smem, kcol, NB);
@@ -785,10 +787,14 @@ hipError_t big_solve_cholesky(const DevP& P, const BigWork& W, hipStream_t s) {
     const int p1 = p0 + kOuter < nt ? p0 + kOuter : nt;
     for (int p = p0; p < p1; ++p) {
       hipLaunchKernelGGL(k_gemm_k128<1>, dim3((NB / kTrsmRows) * (nt - p - 1) + 1, 1), dim3(256), kLdsTrsm, s, P, W.A, ld, p + 1, 0,
-                         p * NB, (const double*)(W.Linv + (long long)p * NB * NB), (double*)nullptr, (double*)nullptr);
+                         p * NB, (const double*)(W.Linv + (long long)p * NB * NB), (double*)nullptr, (double*)nullptr,
+                         (NB / kTrsmRows) * (nt - p - 1) + 1);
       if (p + 1 < p1)  // bring the block's remaining panel columns up to date with panel p (K = 128); factor p + 1
-        hipLaunchKernelGGL(k_gemm_k128<0>, dim3(2 * (nt - p - 1) + 1, 2 * (p1 - p - 1)), dim3(256), kLdsK128Fused, s, P,
-                           W.A, ld, p + 1, p + 1, p * NB, (const double*)nullptr, W.Linv, W.LinvT);
+        // grid.x padded to a multiple of 8: workgroups go to the 8 XCDs round-robin by linear index, so with
+        // that width an XCD keeps the same row tiles for every column tile and finds their panel rows in its L2
+        hipLaunchKernelGGL(k_gemm_k128<0>, dim3((2 * (nt - p - 1) + 1 + 7) / 8 * 8, 2 * (p1 - p - 1)), dim3(256),
+                           kLdsK128Fused, s, P, W.A, ld, p + 1, p + 1, p * NB, (const double*)nullptr, W.Linv, W.LinvT,
+                           2 * (nt - p - 1) + 1);
     }
     const int rest = nt - p1;
     if (rest > 0)  // trailing update with the whole block (K = kOuter * 128); factor panel p1
