@@ -30,7 +30,8 @@
 extern "C" {
 #endif
 
-#define HIPBA_VERSION 100
+/* bumped whenever a struct of this header changes size or layout; hipba_version() returns the library's value */
+#define HIPBA_VERSION 101
 
 /* status codes */
 enum {

@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libhipba.so")
 OK = 0
 ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_OUT_OF_MEMORY, ERR_UNSUPPORTED, ERR_COMM = -1, -2, -3, -4, -5, -6
 CAMERA_Z_FORWARD, CAMERA_X_FORWARD = 0, 1
+ABI_VERSION = 101  # HIPBA_VERSION of the include/hipba.h these ctypes structures mirror
 LOSS_NONE, LOSS_HUBER = 0, 1
 LINEAR_AUTO, LINEAR_DENSE_CHOLESKY, LINEAR_PCG = 0, 1, 2
 CONVERGENCE, NO_CONVERGENCE, FAILURE = 0, 1, 2
@@ -113,6 +114,9 @@ def load_library(path=None):
                           "there is no CPU fallback" % p)
     lib = C.CDLL(p)
     lib.hipba_version.restype = C.c_int
+    if lib.hipba_version() != ABI_VERSION:
+        raise ImportError("%s is ABI version %d, this binding mirrors version %d of include/hipba.h: rebuild with "
+                          "./build.sh" % (p, lib.hipba_version(), ABI_VERSION))
     lib.hipba_last_error.restype = C.c_char_p
     lib.hipba_options_default.argtypes = [C.POINTER(COptions)]
     lib.hipba_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
