@@ -110,8 +110,13 @@ public:
   // reference: void Optimizer::optimize(const std::shared_ptr<Map>& map, const cv::Matx33d& K)
   template <class MapT, class KT>
   void optimize(const std::shared_ptr<MapT>& map, const KT& K) {
-    if (!handle_ && hipba_create(device_, &handle_) != HIPBA_OK)
-      throw std::runtime_error(std::string("hipba_create: ") + hipba_last_error());
+    if (!handle_) {
+      if (hipba_version() != HIPBA_VERSION)
+        throw std::runtime_error("libhipba.so is ABI version " + std::to_string(hipba_version()) +
+                                 ", this adapter was compiled against version " + std::to_string(HIPBA_VERSION));
+      if (hipba_create(device_, &handle_) != HIPBA_OK)
+        throw std::runtime_error(std::string("hipba_create: ") + hipba_last_error());
+    }
     hipba_options options;
     hipba_options_default(&options);
     options.max_num_iterations = 300;          // optimizer.cpp:58
