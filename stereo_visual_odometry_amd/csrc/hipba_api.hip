@@ -89,6 +89,7 @@ struct hipba_device_problem_s {
   long long d2h_bytes = 0;    // device-to-host bytes since the last solve started
   int n_blocks = 0;
   long long S_doubles = 0;
+  bool S_fully_written = false;  // gathered mode, every off-diagonal block has a pair: no word of S needs zeroing
   BigWork big;
   bool has_big = false;
 };
@@ -410,6 +411,12 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
         dest_of[d.pair_begin + q] = dst;
         dest_start[dst + 1]++;
       }
+    }
+    {
+      // the gather stores every off-diagonal block that has a pair and the initialisation every diagonal one
+      bool all = true;
+      for (long long i = 0; i < n_dest && all; ++i) all = dest_start[i + 1] > 0;
+      R->S_fully_written = all;
     }
     for (long long i = 0; i < n_dest; ++i) dest_start[i + 1] += dest_start[i];
     std::vector<long long> cur(dest_start.begin(), dest_start.end() - 1);
@@ -770,7 +777,8 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
   int iterations_run = 0;
   for (int iter = 1; iter <= std::max(lm.max_num_iterations, 0); ++iter) {
     // S is zeroed first so that, unsharded, the camera-block launch can initialise the reduced system too
-    if (R->S_doubles) HIPBA_HIP(hipMemsetAsync(P.S, 0, sizeof(double) * (size_t)R->S_doubles, s));
+    if (R->S_doubles && !(R->S_fully_written && !sharded))
+      HIPBA_HIP(hipMemsetAsync(P.S, 0, sizeof(double) * (size_t)R->S_doubles, s));
     const bool fuse_init = iter > 1 && !sharded;
     if (iter > 1) {
       HIPBA_HIP(launch_camera_blocks(P, lm, 1, fuse_init ? 1 : 0, s));
