@@ -1084,6 +1084,7 @@ __device__ void window_gradient_check(const DevP& P, const LmParams& lm, const W
   double gm = 0.0;
   double g2[1] = {0.0};
   if (mode != kDecide) {
+#pragma unroll 8
     for (int b = wd.pm_blk_begin + threadIdx.x; b < wd.pm_blk_end; b += blockDim.x) {
       gm = fmax(gm, P.gpart[2ll * b]);
       g2[0] += P.gpart[2ll * b + 1];
@@ -1136,6 +1137,8 @@ __device__ __forceinline__ void window_control_body(const DevP& P, const LmParam
   if (!failed && mode != kDecide) {
     const long long nb = (long long)P.n_blk_pm + P.n_blk_vc + P.n_blk_cc;
     const double* p2 = P.partial + nb * kPartialStride;  // second bank: candidate cost
+    // (unrolled: a large window has tens of thousands of blocks, and the loads of one trip do not depend on the last)
+#pragma unroll 8
     for (int b = wd.pm_blk_begin + threadIdx.x; b < wd.pm_blk_end; b += kBlock) {
       const double* pr = P.partial + (long long)b * kPartialStride;
       acc[0] += pr[0]; acc[1] += pr[1]; acc[2] += pr[2];
