@@ -560,6 +560,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (MODE == 0 && col0 > row0 + TI - 1) return;  // wholly above the diagonal
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wr = wave >> 1, wc = wave & 1;
+  // Column sub-tile a of this wave starts at column K128_CT(a).  MODE 0: the wave's half of the tile.  MODE 1: the
+  // inverse is lower triangular, so the 16 columns of sub-tile ct only need the stages c <= ct; the waves take the
+  // sub-tiles {0, 3, 4, 7} and {1, 2, 5, 6}, 18 stage products each instead of 32.
+#define K128_CTILE(a) (2 * (a) + (((a) ^ wc) & 1))
+#define K128_CT(a) (MODE == 0 ? wc * (TJ / 2) + (a) * 16 : K128_CTILE(a) * 16)
   const int lcol = t >> 4, lsub = t & 15;
   const double* Ap = Amat + (long long)kcol * ld + row0;
   const double* Bp = MODE == 0 ? Amat + (long long)kcol * ld + col0 : Linv;
@@ -586,7 +591,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int b = 0; b < MI; ++b)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          cold[a][b][r] = Cp[(long long)(wc * (TJ / 2) + a * 16 + (lane >> 4) + 4 * r) * ld + wr * (TI / 2) + b * 16 + (lane & 15)];
+          cold[a][b][r] = Cp[(long long)(K128_CT(a) + (lane >> 4) + 4 * r) * ld + wr * (TI / 2) + b * 16 + (lane & 15)];
   }
   const bool live = P.ws[0].active && !P.ws[0].solve_failed;  // uniform; tested after the loads are on their way
 
@@ -610,11 +615,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if constexpr ((c) + DEPTH < NCH) K128_GLOAD(slot, (c) + DEPTH);                                               \
     _Pragma("unroll") for (int kk = 0; kk < KC / 4; ++kk) {                                                       \
       const int kr = kk * 4 + (lane >> 4);                                                                        \
-      double fa[MJ], fb[MI];                                                                                      \
-      _Pragma("unroll") for (int m = 0; m < MJ; ++m) fa[m] = sB[buf][kr * LDB + (lane & 15) + wc * (TJ / 2) + m * 16]; \
+      double fb[MI];                                                                                              \
       _Pragma("unroll") for (int m = 0; m < MI; ++m) fb[m] = sA[buf][kr * LDA + (lane & 15) + wr * (TI / 2) + m * 16]; \
-      _Pragma("unroll") for (int a = 0; a < MJ; ++a) _Pragma("unroll") for (int b = 0; b < MI; ++b)               \
-          acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);                     \
+      _Pragma("unroll") for (int a = 0; a < MJ; ++a) {                                                            \
+        if (MODE == 0 || (c) <= K128_CTILE(a)) {                                                                  \
+          const double fa = sB[buf][kr * LDB + (lane & 15) + K128_CT(a)];                                         \
+          _Pragma("unroll") for (int b = 0; b < MI; ++b)                                                          \
+              acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, fb[b], acc[a][b], 0, 0, 0);                    \
+        }                                                                                                         \
+      }                                                                                                           \
     }                                                                                                             \
   }
   K128_STAGE(0) K128_STAGE(1) K128_STAGE(2) K128_STAGE(3) K128_STAGE(4) K128_STAGE(5) K128_STAGE(6) K128_STAGE(7)
@@ -627,7 +636,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int b = 0; b < MI; ++b) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int col = wc * (TJ / 2) + a * 16 + (lane >> 4) + 4 * r;
+        const int col = K128_CT(a) + (lane >> 4) + 4 * r;
         const int row = wr * (TI / 2) + b * 16 + (lane & 15);
         double* dst = Cp + (long long)col * ld + row;
         if (MODE == 0) *dst = cold[a][b][r] - acc[a][b][r];
@@ -661,12 +670,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int rr = 0; rr < RW; rr += 2) {
         const int rl = rr + (lane >> 5), cl = lane & 31;
-        Amat[(long long)(row0 + wr * RW + rl) * ld + kcol + wc * 64 + half * 32 + cl] = stg[rl * TP + cl];
+        Amat[(long long)(row0 + wr * RW + rl) * ld + kcol + K128_CT(2 * half + (cl >> 4)) + (cl & 15)] = stg[rl * TP + cl];
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
   }
+#undef K128_CT
+#undef K128_CTILE
 }
 
 // ---- backward substitution with the blocked factor (the forward one happens inside the factorisation) ----
