@@ -725,30 +725,53 @@ __global__ __launch_bounds__(kTrsvThreads) void k_trsv_bwd(DevP P, const double*
   __shared__ double zk[NB];
   __shared__ double yk[NB];
   __shared__ double part[4][NB];
-  if (!P.ws[0].active || P.ws[0].solve_failed) return;
   const int t = threadIdx.x, r = t & (NB - 1), h = t >> 7;
   const int j = blockIdx.x;  // 0 .. k-1
-  if (t < NB) yk[t] = y[k * NB + t];
-  __syncthreads();
+  const bool last = j == k - 1;
+  // The launch is one link of a chain of dependent launches, so every load that does not depend on another is
+  // issued before anything waits: the tile of the factor, the inverse block the last workgroup needs, z and y.
   const double* Ujk = A + (long long)k * NB * ld + (long long)j * NB;  // rows of block j, columns of block k
+  const double* Li = LinvT_all + (long long)(k - 1) * NB * NB;
+  double u[32], li[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) u[i] = Ujk[(long long)(h * 32 + i) * ld + r];
+  if (last) {
+#pragma unroll
+    for (int i = 0; i < 32; ++i) li[i] = Li[(h * 32 + i) * NB + r];
+  }
+  double zv = 0.0, yv = 0.0;
+  if (t < NB) { zv = z[j * NB + t]; yv = y[k * NB + t]; }
+  if (!P.ws[0].active || P.ws[0].solve_failed) return;
+  if (t < NB) yk[t] = yv;
+  __syncthreads();
   {
     double s0 = 0.0, s1 = 0.0;
-#pragma unroll 8
-    for (int c = h * 32; c < h * 32 + 32; c += 2) {
-      s0 += Ujk[(long long)c * ld + r] * yk[c];
-      s1 += Ujk[(long long)(c + 1) * ld + r] * yk[c + 1];
+#pragma unroll
+    for (int i = 0; i < 32; i += 2) {
+      s0 += u[i] * yk[h * 32 + i];
+      s1 += u[i + 1] * yk[h * 32 + i + 1];
     }
     part[h][r] = s0 + s1;
   }
   __syncthreads();
   if (t < NB) {
-    const double v = z[j * NB + t] - ((part[0][t] + part[1][t]) + (part[2][t] + part[3][t]));
+    const double v = zv - ((part[0][t] + part[1][t]) + (part[2][t] + part[3][t]));
     z[j * NB + t] = v;
     zk[t] = v;
   }
-  if (j != k - 1) return;
+  if (!last) return;
   __syncthreads();
-  trsv_solve_block(LinvT_all + (long long)(k - 1) * NB * NB, zk, part, yk, y + (k - 1) * NB);
+  {
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 32; i += 2) {
+      s0 += li[i] * zk[h * 32 + i];
+      s1 += li[i + 1] * zk[h * 32 + i + 1];
+    }
+    part[h][r] = s0 + s1;
+  }
+  __syncthreads();
+  if (t < NB) y[(k - 1) * NB + t] = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
 }
 
 __global__ void k_store_solution(DevP P, const double* y, int n) {
