@@ -119,7 +119,47 @@ def secondary_measurements(solver):
         "windows": n_w, "windows_per_s": n_w / dt, "lm_iterations_per_s": tot_it / dt, "ms_total": 1e3 * dt,
         "workload": "1024 windows x (10 keyframes, 2000 landmarks, ~14k observations), resident in HBM"}
     dp.free()
+    out["concurrent_sequences"] = concurrent_sequences(solver.device)
     return out
+
+
+def concurrent_sequences(device, n_seq=11, windows_per_seq=8):
+    """Eleven sequences (KITTI 00-10) sharing ONE GPU: a host thread and an engine handle per sequence, every thread
+    solving its keyframe windows back to back (the reference solves one window per 20 frames, so this is the worst
+    case of all sequences asking at once).  Latency of one optimize() call as its caller sees it."""
+    import threading
+    from stereo_visual_odometry_amd import hipba, scenes
+    solvers = [hipba.Solver(device) for _ in range(n_seq)]
+    wins = [[scenes.kitti_like_window(1000 + 16 * q + i)[0] for i in range(windows_per_seq)] for q in range(n_seq)]
+    opts = hipba.reference_production_options()
+    for q in range(n_seq):
+        solvers[q].solve(wins[q][0].copy(), opts, log=False)  # warm-up: arenas grown, code loaded
+    lat = [[] for _ in range(n_seq)]
+    start = threading.Barrier(n_seq + 1)
+
+    def run(q):
+        start.wait()
+        for w in wins[q]:
+            t0 = time.perf_counter()
+            solvers[q].solve(w, opts, log=False)
+            lat[q].append(time.perf_counter() - t0)
+
+    threads = [threading.Thread(target=run, args=(q,)) for q in range(n_seq)]
+    for th in threads:
+        th.start()
+    start.wait()
+    t0 = time.perf_counter()
+    for th in threads:
+        th.join()
+    wall = time.perf_counter() - t0
+    for sv in solvers:
+        sv.close()
+    all_lat = np.sort(np.concatenate([np.asarray(l) for l in lat]))
+    return {"sequences": n_seq, "windows": int(all_lat.size), "windows_per_s": all_lat.size / wall,
+            "latency_ms": {"p50": 1e3 * float(np.percentile(all_lat, 50)), "p95": 1e3 * float(np.percentile(all_lat, 95)),
+                           "max": 1e3 * float(all_lat[-1])},
+            "workload": "%d host threads, one engine handle each, on one GPU; %d KITTI-like 30-keyframe windows per "
+                        "thread solved back to back, host upload included" % (n_seq, windows_per_seq)}
 
 
 def replica_windows(solver, rank, world, fence, n_w=1024):

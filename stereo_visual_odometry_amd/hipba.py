@@ -282,7 +282,8 @@ class Solver:
     def __init__(self, device=0):
         self._lib = load_library()
         self._h = C.c_void_p()
-        _check(self._lib.hipba_create(int(device), C.byref(self._h)))
+        self.device = int(device)
+        _check(self._lib.hipba_create(self.device, C.byref(self._h)))
 
     @property
     def stream(self):
