@@ -148,6 +148,11 @@ struct DevP {
   double* gp;       // [3*n_pm_points]  scaled landmark gradient
   double* scale_p;  // [3*n_pm_points]
   double* S;        // packed upper block-triangular reduced matrices, 36 doubles per 6x6 block
+  // Set for a solve whose every block of S is written in full each iteration and whose reduced system goes to the
+  // dense factorisation: the blocks are then written straight into that solver's column-major lower triangle
+  // (element (r, c) of block (i, j), i <= j, is row 6 j + c of column 6 i + r) and S is not used at all.
+  double* dense_S;
+  int dense_ld;
   double* partial;  // [2 banks][kPartialStride * n_blocks]
   double* gpart;    // [2 * n_blk_pm] landmark gradient max / sum of squares per PM block
   double* wsum;     // [8 * n_windows] per-window sums handed to the all-reduce of sharded solves

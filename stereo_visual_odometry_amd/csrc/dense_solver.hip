@@ -46,7 +46,7 @@ size_t big_work_bytes(int n, int ncam) {
 void big_work_bind(BigWork& W, int n, int ncam, void* base) {
   const size_t npad = rup((size_t)n, NB);
   char* p = static_cast<char*>(base);
-  W.n = n; W.npad = (int)npad;
+  W.n = n; W.npad = (int)npad; W.ld = (int)dense_ld(npad);
   W.A = reinterpret_cast<double*>(p); p += rup(dense_ld(npad) * (npad + NB) * 8, 256);
   W.Linv = reinterpret_cast<double*>(p); p += rup((npad / NB) * NB * NB * 8, 256);
   W.LinvT = reinterpret_cast<double*>(p); p += rup((npad / NB) * NB * NB * 8, 256);
@@ -67,6 +67,20 @@ __global__ void k_unpack_lower(DevP P, double* A, int ld) {
   const double v = P.S[P.wd[0].S_off + 36ll * tri_index(bi, bi, ncam) + e];
   const int row = 6 * bj + c, col = 6 * bi + a;
   if (row >= col) A[(long long)col * ld + row] = v;
+}
+
+// Zeroes the lower triangle of the leading n x n part (one workgroup per column): what a memset of the packed
+// matrix is to the unpacking path when the elimination writes its blocks straight into A but leaves some untouched.
+__global__ __launch_bounds__(256) void k_zero_lower(DevP P, double* A, int n, int ld) {
+  if (!P.ws[0].active) return;
+  const int col = blockIdx.x;
+  double* c = A + (long long)col * ld;
+  const int r0 = col & ~1;  // 16-byte aligned start: ld is even; the one word above the diagonal is free to zero
+  for (int r = r0 + 2 * threadIdx.x; r < n; r += 512) *reinterpret_cast<double2*>(c + r) = make_double2(0.0, 0.0);
+}
+hipError_t big_zero_lower(const DevP& P, const BigWork& W, hipStream_t s) {
+  hipLaunchKernelGGL(k_zero_lower, dim3(W.n), dim3(256), 0, s, P, W.A, W.n, W.ld);
+  return hipGetLastError();
 }
 
 // rows beyond n: identity on the padded diagonal, and b^T as row npad -- the first row of one extra tile row.
@@ -803,7 +817,8 @@ hipError_t big_solve_cholesky(const DevP& P, const BigWork& W, hipStream_t s) {
   const int n = W.n, npad = W.npad, nt = npad / NB;
   const int ld = (int)dense_ld(npad);  // one extra tile row: b^T rides along as row npad (see k_pad_init)
   const int ncam = n / 6;
-  hipLaunchKernelGGL(k_unpack_lower, dim3((ncam * 36 + 255) / 256, ncam), dim3(256), 0, s, P, W.A, ld);
+  if (!P.dense_S)  // otherwise the elimination has written the blocks where they belong
+    hipLaunchKernelGGL(k_unpack_lower, dim3((ncam * 36 + 255) / 256, ncam), dim3(256), 0, s, P, W.A, ld);
   hipLaunchKernelGGL(k_pad_init, dim3((npad + 255) / 256), dim3(256), 0, s, P, W.A, n, npad, ld);
   // Two-level right-looking factorisation.  Panels of 128 columns are grouped in blocks of kOuter
   // panels.  Inside a block a freshly factored panel only updates the block's remaining panel columns

@@ -747,6 +747,11 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
   // windows the in-LDS solver takes also accumulate b (and a small enough S) in LDS
   const int small_ncam = small ? R->max_ncam : 0;
   const int schur_parts = schur_parts_for(P.n_windows, R->max_pm_blocks);
+  // gathered elimination (one writer per block of the reduced matrix) + the dense factorisation: the blocks go
+  // straight into the factorisation's matrix, no packed copy
+  const bool direct = P.n_chunks > 0 && !sharded && !small && solver == HIPBA_LINEAR_DENSE_CHOLESKY;
+  P.dense_S = direct ? R->big.A : nullptr;
+  P.dense_ld = direct ? R->big.ld : 0;
 
   auto allreduce = [&](double* buf, size_t n, int op) -> int {
     if (!sharded) return 0;
@@ -777,8 +782,11 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
   int iterations_run = 0;
   for (int iter = 1; iter <= std::max(lm.max_num_iterations, 0); ++iter) {
     // S is zeroed first so that, unsharded, the camera-block launch can initialise the reduced system too
-    if (R->S_doubles && !(R->S_fully_written && !sharded))
+    if (direct) {
+      if (!R->S_fully_written) HIPBA_HIP(big_zero_lower(P, R->big, s));
+    } else if (R->S_doubles && !(R->S_fully_written && !sharded)) {
       HIPBA_HIP(hipMemsetAsync(P.S, 0, sizeof(double) * (size_t)R->S_doubles, s));
+    }
     const bool fuse_init = iter > 1 && !sharded;
     if (iter > 1) {
       HIPBA_HIP(launch_camera_blocks(P, lm, 1, fuse_init ? 1 : 0, s));
@@ -1188,6 +1196,9 @@ int hipba_time_kernel(hipba_handle h, hipba_device_problem dp, const hipba_optio
   const bool small = max_n <= kSmallMaxN;
   const int small_ncam = small ? dp->max_ncam : 0;
   const int schur_parts = schur_parts_for(P.n_windows, dp->max_pm_blocks);
+  const bool direct = P.n_chunks > 0 && !small && o.linear_solver != HIPBA_LINEAR_PCG;  // as in a solve
+  P.dense_S = direct ? dp->big.A : nullptr;
+  P.dense_ld = direct ? dp->big.ld : 0;
   // bring the work arrays to the state of a first iteration (parameters are not modified)
   auto prepare = [&]() -> int {
     HIPBA_HIP(launch_cost(P, lm, 0, n_act_blk, 0, 1, false, s));
@@ -1196,7 +1207,8 @@ int hipba_time_kernel(hipba_handle h, hipba_device_problem dp, const hipba_optio
     HIPBA_HIP(launch_camera_blocks(P, lm, 0, 0, s));
     HIPBA_HIP(launch_make_scale_c(P, lm.jacobi_scaling, s));
     HIPBA_HIP(launch_point_colnorm(P, lm, s));
-    if (dp->S_doubles) HIPBA_HIP(hipMemsetAsync(P.S, 0, sizeof(double) * (size_t)dp->S_doubles, s));
+    if (direct) HIPBA_HIP(big_zero_lower(P, dp->big, s));
+    else if (dp->S_doubles) HIPBA_HIP(hipMemsetAsync(P.S, 0, sizeof(double) * (size_t)dp->S_doubles, s));
     HIPBA_HIP(launch_init_reduced(P, lm, 1, s));
     HIPBA_HIP(launch_point_schur(P, lm, small_ncam, schur_parts, s));
     return HIPBA_OK;
@@ -1245,7 +1257,8 @@ int hipba_time_kernel(hipba_handle h, hipba_device_problem dp, const hipba_optio
     if (kernel == HIPBA_KERNEL_REDUCED_SOLVE) {
       // the factorisation destroys nothing it needs again, but the Schur matrix must be rebuilt per repeat
       for (int i = 0; i < repeats && !rc; ++i) {
-        if (dp->S_doubles) HIPBA_HIP(hipMemsetAsync(P.S, 0, sizeof(double) * (size_t)dp->S_doubles, s));
+        if (direct) HIPBA_HIP(big_zero_lower(P, dp->big, s));
+        else if (dp->S_doubles) HIPBA_HIP(hipMemsetAsync(P.S, 0, sizeof(double) * (size_t)dp->S_doubles, s));
         HIPBA_HIP(launch_init_reduced(P, lm, 1, s));
         HIPBA_HIP(launch_point_schur(P, lm, small_ncam, schur_parts, s));
         HIPBA_HIP(hipEventRecord(e0, s));

@@ -34,6 +34,7 @@ hipError_t launch_residual_jacobian(const CameraK& K, const LmParams& lm, int ap
 struct BigWork {
   int n = 0;           // 6 * ncam
   int npad = 0;        // n rounded up to the factorisation panel width
+  int ld = 0;          // leading dimension of A
   double* A = nullptr;     // [(npad + NB)^2] column-major, lower triangle holds S then its Cholesky factor;
                            // row npad carries b^T, then z^T = (L^-1 b)^T
   double* Linv = nullptr;  // [npad/NB][NB*NB] inverses of the diagonal blocks of L
@@ -48,6 +49,8 @@ size_t big_work_bytes(int n, int ncam);
 void big_work_bind(BigWork& W, int n, int ncam, void* base);
 // Cholesky: S (packed, P.S) y = b (P.b) -> P.yc; marks ws.solve_failed when S is not positive definite
 hipError_t big_solve_cholesky(const DevP& P, const BigWork& W, hipStream_t s);
+// zeroes the lower triangle of W.A: for solves whose elimination writes the blocks of S straight into it (DevP::dense_S)
+hipError_t big_zero_lower(const DevP& P, const BigWork& W, hipStream_t s);
 // block-Jacobi preconditioned conjugate gradients on the packed S
 hipError_t big_solve_pcg(const DevP& P, const BigWork& W, int max_iter, double tol, hipStream_t s);
 

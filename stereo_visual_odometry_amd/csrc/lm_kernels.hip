@@ -166,7 +166,11 @@ __device__ __forceinline__ void init_reduced_pose(const DevP& P, const LmParams&
         double dg = fmin(fmax(v, lm.min_lm_diagonal), lm.max_lm_diagonal);
         v += dg * inv_radius;
       }
-      if (owner) Sb[6 * i + j] = v;  // sharded solves: one rank contributes U + D^2 and g_c
+      if (P.dense_S) {
+        if (j >= i) P.dense_S[(long long)(6 * slot + i) * P.dense_ld + 6 * slot + j] = v;  // lower triangle only
+      } else if (owner) {
+        Sb[6 * i + j] = v;  // sharded solves: one rank contributes U + D^2 and g_c
+      }
     }
   }
   double neg[6];
@@ -740,12 +744,23 @@ __global__ __launch_bounds__(kBlock) void k_schur_gather(DevP P, LmParams lm) {
   if (lane < 36) sT[lane * kGatherRow + 64] = 0.0;
   if (lane < 16) sT[36 * kGatherRow + lane] = 0.0;
   int cur = -1, cur_diag = 0;  // destination being summed by lanes 0-35 (wave-uniform)
+  int cur_a = 0, cur_b = 0;    // its row and column slot
   double acc = 0.0;
+  double* const dense = P.dense_S;
+  const int er = e / 6, ec = e % 6;
   auto flush = [&]() {
     if (cur >= 0 && lane < 36) {
-      double* dst = S + 36ll * cur + e;
-      if (cur_diag) atomic_add_f64(dst, -acc);
-      else *dst = -acc;
+      if (dense) {
+        // straight into the dense lower triangle: consecutive destinations of a row slot are consecutive 48-byte
+        // pieces of the same six columns
+        double* dst = dense + (long long)(6 * cur_a + er) * P.dense_ld + 6 * cur_b + ec;
+        if (!cur_diag) *dst = -acc;
+        else if (ec >= er) atomic_add_f64(dst, -acc);
+      } else {
+        double* dst = S + 36ll * cur + e;
+        if (cur_diag) atomic_add_f64(dst, -acc);
+        else *dst = -acc;
+      }
     }
   };
   // software pipeline: the list entries run two batches ahead of the arithmetic and the landmark records one,
@@ -848,6 +863,8 @@ __global__ __launch_bounds__(kBlock) void k_schur_gather(DevP P, LmParams lm) {
         flush();
         cur = du;
         cur_diag = __builtin_amdgcn_readlane(diag, u0);
+        cur_a = __builtin_amdgcn_readlane(a, u0);
+        cur_b = __builtin_amdgcn_readlane(b, u0);
         acc = 0.0;
       }
       const int len = u1 - u0;
