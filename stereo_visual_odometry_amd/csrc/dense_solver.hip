@@ -153,7 +153,7 @@ __device__ __forceinline__ void tile_store_t(double* T, v4d v, int lane) {  // s
   for (int r = 0; r < 4; ++r) T[((lane >> 4) + 4 * r) * TB + (lane & 15)] = v[r];
 }
 
-// LDS of one panel factorisation: 36 lower tiles, the failure word, the reciprocal diagonal
+// LDS of one panel factorisation: 36 lower tiles, the failure word (and 1 KB to spare)
 constexpr size_t kPotrfLds = (size_t)(NTL * (NTL + 1) / 2) * kTile * 8 + 64 + NB * 8;
 
 // Factorisation of diagonal block k by the calling workgroup (256 threads, kPotrfLds bytes at smem).
@@ -165,7 +165,6 @@ __device__ __forceinline__ void potrf_block(const DevP& P, double* A, int ld, in
                                             double* smem, int kcol0, int K) {
   double* Lt = smem;                                   // 36 tiles; the diagonal ones hold their inverses at the end
   int& fail = *reinterpret_cast<int*>(smem + (NTL * (NTL + 1) / 2) * kTile);
-  double* rdiag = smem + (NTL * (NTL + 1) / 2) * kTile + 8;  // [NB] reciprocals of the factor's diagonal
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   double* Akk = A + (long long)k * NB * ld + (long long)k * NB;
   HIPBA_CYCLES(0);
@@ -223,15 +222,22 @@ __device__ __forceinline__ void potrf_block(const DevP& P, double* A, int ld, in
   __syncthreads();
   HIPBA_CYCLES(1);
 
-  // (a) Cholesky of the 16x16 diagonal tile jd by one wave, in registers: lane r holds row r, the pivots and
-  // multipliers travel between lanes as wave-uniform scalars (v_readlane).  The tile's inverse is not needed
-  // inside the loop (the panel below is solved by substitution) and is formed for all eight tiles at once later.
+  // (a) Cholesky of the 16x16 diagonal tile jd by one wave, in registers: lane r < 16 holds row r, the pivots and
+  // multipliers travel between lanes as wave-uniform scalars (v_readlane).  The tile's inverse comes out of the same
+  // instructions: lanes 16-31 start from the columns of the identity and go through the very same scalings and
+  // multiply-subtracts (forward substitution wants exactly the multipliers the factorisation broadcasts), so lane
+  // 16 + r ends up with column r of L^-1.  The factor goes straight to global memory; LDS keeps the inverse, which
+  // is what the panel below, the block inverse and the panel solve's caller need.
   auto diag_tile = [&](int jd) {
     double* D = Lt + ltile(jd, jd);
     const int r = lane & 15;
-    double x[TB], rinv[TB];
+    const bool inverse_half = (lane & 16) != 0;
+    double x[TB];
 #pragma unroll
-    for (int c = 0; c < TB; ++c) x[c] = D[c * TB + r];
+    for (int c = 0; c < TB; ++c) {
+      const double a = D[c * TB + r];
+      x[c] = inverse_half ? (c == r ? 1.0 : 0.0) : a;
+    }
     bool bad = false;
 #pragma unroll
     for (int c = 0; c < TB; ++c) {
@@ -241,19 +247,20 @@ __device__ __forceinline__ void potrf_block(const DevP& P, double* A, int ld, in
       double inv = __builtin_amdgcn_rsq(d);
       inv = inv * (1.5 - 0.5 * d * inv * inv);
       inv = inv * (1.5 - 0.5 * d * inv * inv);
-      rinv[c] = inv;
       x[c] *= inv;
 #pragma unroll
-      for (int kc = c + 1; kc < TB; ++kc) x[kc] -= x[c] * bcast_lane(x[c], kc);
+      for (int kc = c + 1; kc < TB; ++kc) x[kc] -= x[c] * bcast_lane(x[c], kc);  // lane kc < 16: L(kc, c)
     }
     if (bad) {
       if (lane == 0) fail = 1;
     } else if (lane < TB) {
+      double* G = Akk + (long long)(TB * jd) * ld + TB * jd + r;
 #pragma unroll
-      for (int c = 0; c < TB; ++c) {
-        if (c <= r) D[c * TB + r] = x[c];
-        if (c == r) rdiag[jd * TB + c] = rinv[c];
-      }
+      for (int c = 0; c < TB; ++c)
+        if (c <= r) G[(long long)c * ld] = x[c];
+    } else if (lane < 2 * TB) {
+#pragma unroll
+      for (int c = 0; c < TB; ++c) D[r * TB + c] = x[c];  // column r of the inverse (zero above the diagonal)
     }
   };
   if (wave == 0) diag_tile(0);
@@ -261,25 +268,16 @@ __device__ __forceinline__ void potrf_block(const DevP& P, double* A, int ld, in
   for (int j = 0; j < NTL; ++j) {
     if (j == 2) HIPBA_CYCLES(5);
     if (fail) break;
-    // (b) panel below the diagonal tile: L(i,j) = A(i,j) L(j,j)^-T, one lane per row, forward substitution with
-    // the diagonal tile read from LDS (every lane reads the same words: broadcasts)
-    if (t < TB * (NTL - 1 - j)) {
-      double* T = Lt + ltile(j + 1 + (t >> 4), j) + (t & 15);
-      const double* D = Lt + ltile(j, j);
-      const double* ri = rdiag + j * TB;
-      double x[TB];
-#pragma unroll
-      for (int c = 0; c < TB; ++c) x[c] = T[c * TB];
-      // right-looking: a finished column is taken out of all later ones at once (independent multiply-adds;
-      // the dependency chain is two operations per column instead of one per term)
-#pragma unroll
-      for (int c = 0; c < TB; ++c) {
-        x[c] *= ri[c];
-#pragma unroll
-        for (int c2 = c + 1; c2 < TB; ++c2) x[c2] -= x[c] * D[c * TB + c2];
+    // (b) panel below the diagonal tile: L(i,j) = A(i,j) L(j,j)^-T, one matrix-core tile product each with the
+    // tile's inverse (the result replaces the tile: every lane has read its operands before the first store)
+    {
+      const double* Dinv = Lt + ltile(j, j);
+      for (int i = j + 1 + wave; i < NTL; i += 4) {
+        double* T = Lt + ltile(i, j);
+        v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+        acc = mfma_tile<false>(Dinv, T, acc, lane);
+        tile_store_t(T, acc, lane);
       }
-#pragma unroll
-      for (int c = 0; c < TB; ++c) T[c * TB] = x[c];
     }
     __syncthreads();
     if (j == 2) HIPBA_CYCLES(6);
@@ -317,37 +315,13 @@ __device__ __forceinline__ void potrf_block(const DevP& P, double* A, int ld, in
     if (t == 0) P.ws[0].solve_failed = 1;
     return;
   }
-  // factor back to global memory (lower part only)
+  // factor back to global memory (the diagonal tiles went out as they were factored)
   {
     const int q = t >> 4, pr = t & 15;
 #pragma unroll
     for (int bi = 0; bi < NTL; ++bi)
 #pragma unroll
-      for (int bj = 0; bj <= bi; ++bj)
-        if (bi > bj || pr >= q) Akk[(long long)(TB * bj + q) * ld + TB * bi + pr] = Lt[ltile(bi, bj) + t];
-  }
-  // inverses of the eight diagonal tiles, all at once: 16 lanes per tile, lane r forms column r by forward
-  // substitution with the tile read from LDS; the inverse then replaces the tile (the factor is already out)
-  {
-    const int tl = wave * 4 + (lane >> 4), r = lane & 15;
-    double y[TB];
-    if (wave < 2) {
-      const double* D = Lt + ltile(tl, tl);
-      const double* ri = rdiag + tl * TB;
-#pragma unroll
-      for (int i = 0; i < TB; ++i) y[i] = (i == r) ? 1.0 : 0.0;
-#pragma unroll
-      for (int tt = 0; tt < TB; ++tt) {
-        y[tt] *= ri[tt];
-#pragma unroll
-        for (int i = tt + 1; i < TB; ++i) y[i] -= D[tt * TB + i] * y[tt];
-      }
-    }
-    __syncthreads();
-    if (wave < 2) {
-#pragma unroll
-      for (int c = 0; c < TB; ++c) Lt[ltile(tl, tl) + r * TB + c] = y[c];
-    }
+      for (int bj = 0; bj < bi; ++bj) Akk[(long long)(TB * bj + q) * ld + TB * bi + pr] = Lt[ltile(bi, bj) + t];
   }
   __syncthreads();
   HIPBA_CYCLES(3);
