@@ -92,6 +92,13 @@ struct hipba_device_problem_s {
   bool S_fully_written = false;  // gathered mode, every off-diagonal block has a pair: no word of S needs zeroing
   BigWork big;
   bool has_big = false;
+  // end-of-solve snapshot in the handle's pinned staging buffer (small one-shot solves): the control words and both
+  // parameter buffers, fetched with the solve's own final synchronisation so that reading the result back costs no
+  // further round trip over the host link
+  bool tail_valid = false;
+  const WinState* tail_ws = nullptr;
+  const double* tail_poses[2] = {nullptr, nullptr};
+  const double* tail_points[2] = {nullptr, nullptr};
 };
 
 namespace {
@@ -728,7 +735,7 @@ void print_progress(const hipba_iteration* log, int n) {
 
 // ---- the LM loop ---------------------------------------------------------------------------------
 int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o, const hipba_comm* comm,
-           hipba_summary* summaries) {
+           hipba_summary* summaries, bool fetch_tail = false) {
   const double t0 = now_s();
   DevP P = R->P;
   hipStream_t s = h->stream;
@@ -835,7 +842,9 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
     if (sharded || P.n_windows != 1) HIPBA_HIP(launch_count_active(P, R->d_count + slot, s));
     HIPBA_HIP(hipMemcpyAsync(h->h_count + slot, R->d_count + slot, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPBA_HIP(hipEventRecord(h->poll_ev[slot], s));
-    const int lag = (small && !sharded && P.n_windows <= 8) ? 2 : 0;
+    // (a window with a few thousand observations keeps the GPU busy for longer than the host needs to see a count
+    // and queue a pass: one pass of lag is enough there and costs one idle pass at the end instead of two)
+    const int lag = (small && !sharded && P.n_windows <= 8) ? (P.n_act_obs >= 8000 ? 1 : 2) : 0;
     if (iter - lag >= 1) {
       const int seen = (iter - lag) & 3;
       HIPBA_HIP(hipEventSynchronize(h->poll_ev[seen]));
@@ -844,13 +853,36 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
   }
 #undef AR
   (void)iterations_run;
-  HIPBA_HIP(hipStreamSynchronize(s));
-  const double t1 = now_s();
-
   // summaries
   std::vector<WinState> ws(P.n_windows);
-  HIPBA_HIP(hipMemcpy(ws.data(), P.ws, sizeof(WinState) * P.n_windows, hipMemcpyDeviceToHost));
-  R->d2h_bytes = (long long)sizeof(WinState) * P.n_windows;
+  R->tail_valid = false;
+  auto rup256 = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  const size_t ws_bytes = rup256(sizeof(WinState) * (size_t)P.n_windows);
+  const size_t pose_bytes = rup256(sizeof(double) * 7 * (size_t)P.n_poses), point_bytes = rup256(sizeof(double) * 3 * (size_t)P.n_pm_points);
+  const size_t tail_bytes = ws_bytes + 2 * (pose_bytes + point_bytes);
+  if (fetch_tail && tail_bytes <= ((size_t)1 << 20) && ensure_staging(h, tail_bytes) == HIPBA_OK) {
+    // one round trip instead of three: everything the caller will read travels behind the last kernel
+    char* st = static_cast<char*>(h->staging);
+    HIPBA_HIP(hipMemcpyAsync(st, P.ws, sizeof(WinState) * P.n_windows, hipMemcpyDeviceToHost, s));
+    R->tail_ws = reinterpret_cast<const WinState*>(st);
+    size_t at = ws_bytes;
+    for (int k = 0; k < 2; ++k) {
+      if (P.n_poses) HIPBA_HIP(hipMemcpyAsync(st + at, P.poses[k], sizeof(double) * 7 * P.n_poses, hipMemcpyDeviceToHost, s));
+      R->tail_poses[k] = reinterpret_cast<const double*>(st + at); at += pose_bytes;
+      if (P.n_pm_points) HIPBA_HIP(hipMemcpyAsync(st + at, P.points[k], sizeof(double) * 3 * P.n_pm_points, hipMemcpyDeviceToHost, s));
+      R->tail_points[k] = reinterpret_cast<const double*>(st + at); at += point_bytes;
+    }
+    HIPBA_HIP(hipStreamSynchronize(s));
+    memcpy(ws.data(), st, sizeof(WinState) * P.n_windows);
+    R->tail_valid = true;
+    R->d2h_bytes = (long long)sizeof(WinState) * P.n_windows + 2 * 8ll * (7ll * P.n_poses + 3ll * P.n_pm_points);
+  } else {
+    HIPBA_HIP(hipStreamSynchronize(s));
+    HIPBA_HIP(hipMemcpy(ws.data(), P.ws, sizeof(WinState) * P.n_windows, hipMemcpyDeviceToHost));
+    R->d2h_bytes = (long long)sizeof(WinState) * P.n_windows;
+  }
+  const double t1 = now_s();
+
   std::vector<hipba_iteration> log;
   bool want_log = o.minimizer_progress_to_stdout != 0;
   for (int w = 0; w < P.n_windows && !want_log; ++w) want_log = summaries[w].iteration_log != nullptr;
@@ -901,9 +933,16 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
 int download_all(hipba_handle_s* h, hipba_device_problem_s* R, hipba_problem* probs, const hipba_summary* summaries) {
   const DevP& P = R->P;
   std::vector<WinState> ws(P.n_windows);
+  std::vector<double> poses[2], points[2];
+  const double* hp[2] = {nullptr, nullptr};
+  const double* hq[2] = {nullptr, nullptr};
+  if (R->tail_valid) {
+    // the solve has already brought everything into the pinned staging buffer
+    memcpy(ws.data(), R->tail_ws, sizeof(WinState) * P.n_windows);
+    for (int k = 0; k < 2; ++k) { hp[k] = R->tail_poses[k]; hq[k] = R->tail_points[k]; }
+  } else {
   HIPBA_HIP(hipMemcpy(ws.data(), P.ws, sizeof(WinState) * P.n_windows, hipMemcpyDeviceToHost));
   R->d2h_bytes += (long long)sizeof(WinState) * P.n_windows;
-  std::vector<double> poses[2], points[2];
   for (int k = 0; k < 2; ++k) {
     if (P.n_windows == 1 && k != ws[0].sel) continue;  // one window: only the buffer that holds x
     poses[k].resize(std::max<size_t>(7 * (size_t)P.n_poses, 7));
@@ -911,19 +950,21 @@ int download_all(hipba_handle_s* h, hipba_device_problem_s* R, hipba_problem* pr
     if (P.n_poses) HIPBA_HIP(hipMemcpyAsync(poses[k].data(), P.poses[k], sizeof(double) * 7 * P.n_poses, hipMemcpyDeviceToHost, h->stream));
     if (P.n_pm_points) HIPBA_HIP(hipMemcpyAsync(points[k].data(), P.points[k], sizeof(double) * 3 * P.n_pm_points, hipMemcpyDeviceToHost, h->stream));
     R->d2h_bytes += 8ll * (7ll * P.n_poses + 3ll * P.n_pm_points);
+    hp[k] = poses[k].data(); hq[k] = points[k].data();
   }
   HIPBA_HIP(hipStreamSynchronize(h->stream));
+  }
   for (int w = 0; w < P.n_windows; ++w) {
     if (summaries && summaries[w].termination_type == HIPBA_FAILURE) continue;  // Ceres: solution not usable
     const int sel = ws[w].sel;
     const WinMeta& m = R->meta[w];
-    if (m.n_poses) memcpy(probs[w].poses, poses[sel].data() + 7ll * m.pose_base, sizeof(double) * 7 * m.n_poses);
+    if (m.n_poses) memcpy(probs[w].poses, hp[sel] + 7ll * m.pose_base, sizeof(double) * 7 * m.n_poses);
     for (int i = 0; i < m.n_points; ++i) {
       const int dp = m.dp_of[i];
       if (dp < P.n_pm_points) {
-        probs[w].points[3 * i] = points[sel][3ll * dp];
-        probs[w].points[3 * i + 1] = points[sel][3ll * dp + 1];
-        probs[w].points[3 * i + 2] = points[sel][3ll * dp + 2];
+        probs[w].points[3 * i] = hq[sel][3ll * dp];
+        probs[w].points[3 * i + 1] = hq[sel][3ll * dp + 1];
+        probs[w].points[3 * i + 2] = hq[sel][3ll * dp + 2];
       }
     }
   }
@@ -1020,7 +1061,7 @@ int hipba_solve_batched(hipba_handle h, int32_t n_windows, hipba_problem* proble
   int rc = build_resident(h, n_windows, problems, true, std::max(o.max_num_iterations, 0) + 1, false, &R);
   if (rc) return rc;
   const double t1 = now_s();
-  rc = run_lm(h, R, o, nullptr, summaries);
+  rc = run_lm(h, R, o, nullptr, summaries, true);
   if (!rc) rc = download_all(h, R, problems, summaries);
   const long long upload_bytes = R->upload_bytes, d2h_bytes = R->d2h_bytes + 4ll * (n_windows > 0 ? summaries[0].num_linear_solves : 0);
   free_resident(R);

@@ -138,8 +138,9 @@ def test_kitti_like_window_matches_oracle(solver, oracle, seed):
     assert np.abs(g.poses - o.poses).max() <= ATOL_STATE and np.abs(g.points - o.points).max() <= ATOL_STATE
     assert_logs_match(s["iterations"], oits)
     assert s["num_active_poses"] == 29 and s["num_active_observations"] == so["num_active_obs"]
-    # what crossed the host link: the window once up (at least its own arrays), the solution and the
-    # control words back (one pose/point buffer, not both)
+    # what crossed the host link: the window once up (at least its own arrays); the control words and the
+    # parameter buffers back (a one-shot solve of a small window fetches both of its double buffers behind the
+    # last kernel: one round trip instead of three)
     window_bytes = 8 * (prob.poses.size + prob.points.size + prob.obs_uv.size)
     assert window_bytes <= s["bytes_host_to_device"] <= 4 * window_bytes
     assert 8 * (prob.poses.size + 3 * s["num_active_points"]) <= s["bytes_device_to_host"] <= window_bytes
