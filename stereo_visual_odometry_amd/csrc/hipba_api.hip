@@ -335,36 +335,57 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   // ---- blocks + pair lists -----------------------------------------------------------------------
   std::vector<BlockDesc> blocks;
   std::vector<unsigned short> pairs;
+  // The pair list of a block: (i, j), i <= j, over the observations of each of its landmarks whose poses are
+  // variable.  Only the sizes are fixed here (every list 16-byte aligned: blocks load them as uint4); the lists are
+  // written further down, already in the order the accumulation mode wants.
+  long long pairs_total = 0;
   for (int w = 0; w < nw; ++w) {
     wd[w].pm_blk_begin = (int)blocks.size();
     int pp = wd[w].pp_begin;
     while (pp < wd[w].pp_end) {
       BlockDesc d{};
       d.obs_begin = pp_start[pp];
-      while (pairs.size() % 8) pairs.push_back(kPairPad);  // 16-byte aligned lists: blocks load them as uint4
-      d.pair_begin = (long long)pairs.size();
+      pairs_total = (pairs_total + 7) & ~7ll;
+      d.pair_begin = pairs_total;
       d.window = w;
       d.kind = 0;
-      int n = 0;
+      int n = 0, np = 0;
       while (pp < wd[w].pp_end && n + (int)(pp_start[pp + 1] - pp_start[pp]) <= kBlock) {
-        const int s0 = n, s1 = n + (int)(pp_start[pp + 1] - pp_start[pp]);
-        for (int i = s0; i < s1; ++i) {
-          if (pose_gslot[obs_pose[d.obs_begin + i]] < 0) continue;
-          for (int j = i; j < s1; ++j) {
-            if (pose_gslot[obs_pose[d.obs_begin + j]] < 0) continue;
-            pairs.push_back((unsigned short)(i | (j << 8)));
-          }
-        }
+        const int s1 = n + (int)(pp_start[pp + 1] - pp_start[pp]);
+        int v = 0;
+        for (int i = n; i < s1; ++i) v += pose_gslot[obs_pose[d.obs_begin + i]] >= 0;
+        np += v * (v + 1) / 2;
         n = s1;
         ++pp;
       }
       d.n_obs = n;
-      d.n_pairs = (int)((long long)pairs.size() - d.pair_begin);
+      d.n_pairs = np;
+      pairs_total += np;
       blocks.push_back(d);
     }
     wd[w].pm_blk_end = (int)blocks.size();
   }
-  for (int i = 0; i < 8; ++i) pairs.push_back(kPairPad);    // whole-uint4 reads of the last list stay inside
+  pairs_total = ((pairs_total + 7) & ~7ll) + 8;              // whole-uint4 reads of the last list stay inside
+  pairs.assign((size_t)pairs_total, kPairPad);
+  // plain generation order (landmark by landmark, i then j): the gathered mode and the sorting fallback start from it
+  auto generate_pairs = [&](const BlockDesc& d) {
+    const int w = d.window;
+    (void)w;
+    long long q = d.pair_begin;
+    // landmark boundaries inside the block: consecutive observations of one landmark share obs_dp
+    for (int s0 = 0; s0 < d.n_obs;) {
+      int s1 = s0 + 1;
+      while (s1 < d.n_obs && obs_dp[d.obs_begin + s1] == obs_dp[d.obs_begin + s0]) ++s1;
+      for (int i = s0; i < s1; ++i) {
+        if (pose_gslot[obs_pose[d.obs_begin + i]] < 0) continue;
+        for (int j = i; j < s1; ++j) {
+          if (pose_gslot[obs_pose[d.obs_begin + j]] < 0) continue;
+          pairs[q++] = (unsigned short)(i | (j << 8));
+        }
+      }
+      s0 = s1;
+    }
+  };
   const int n_blk_pm = (int)blocks.size();
   {
     long long cur = n_pm_obs;
@@ -404,6 +425,8 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   const bool staged = nw == 1 && max_ncam > 20 && max_ncam <= 0xffff && pairs.size() >= (size_t)2000000 &&
                       n_pm_obs < 0xffffffffll;
   if (staged) {
+    for (const BlockDesc& d : blocks)
+      if (d.kind == 0) generate_pairs(d);
     const int ncam = wd[0].ncam;
     const long long n_dest = (long long)ncam * (ncam + 1) / 2;
     std::vector<long long> dest_start(n_dest + 1, 0);
@@ -473,11 +496,10 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
     std::vector<std::vector<int>> nruns_of(n_thr);
     auto group_range = [&](int ti, int b0, int b1) {
       // counting sort over the destinations a block touches, in order of first appearance
-      std::vector<int> count, touched, key;
+      std::vector<int> count, touched;
       std::vector<std::pair<long long, int>> keyed;   // fallback when a count array would be too large
       const bool counting = n_dest_max <= (1ll << 22);
       if (counting) count.assign(n_dest_max, 0);
-      std::vector<unsigned short> out;
       runs_of[ti].reserve(pairs.size() / (n_thr * 2) + 16);
       nruns_of[ti].reserve(b1 - b0);
       for (int bi = b0; bi < b1; ++bi) {
@@ -490,17 +512,34 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
             ++nr;
           }
         };
-        int lane_slot[kBlock];  // window slot of each observation of the block (looked up once, not per pair)
-        for (int i = 0; i < d.n_obs; ++i) lane_slot[i] = pose_gslot[obs_pose[d.obs_begin + i]] - cam_base;
-        auto dest_of_pair = [&](unsigned short pr) { return tri_index(lane_slot[pr & 0xff], lane_slot[pr >> 8], ncam); };
+        int lane_slot[kBlock];  // window slot of each observation of the block (looked up once, not per pair); -1: constant pose
+        for (int i = 0; i < d.n_obs; ++i) {
+          const int g = pose_gslot[obs_pose[d.obs_begin + i]];
+          lane_slot[i] = g < 0 ? -1 : g - cam_base;
+        }
         if (counting) {
-          key.resize(d.n_pairs);
-          out.resize(d.n_pairs);
+          // Two sweeps over the block's pairs in generation order (landmark by landmark, i then j >= i), neither of
+          // which stores a key: the first counts the pairs of every destination and notes the destinations in order of
+          // first appearance, the second drops each pair at its destination's cursor.
+          long long row_base[kBlock];  // tri_index(slot_i, slot_j) = row_base[i] + slot_j
+          int lm_end[kBlock];          // one past the last observation of lane i's landmark
+          for (int s0 = 0; s0 < d.n_obs;) {
+            int s1 = s0 + 1;
+            while (s1 < d.n_obs && obs_dp[d.obs_begin + s1] == obs_dp[d.obs_begin + s0]) ++s1;
+            for (int i = s0; i < s1; ++i) {
+              lm_end[i] = s1;
+              row_base[i] = lane_slot[i] < 0 ? 0 : tri_index(lane_slot[i], lane_slot[i], ncam) - lane_slot[i];
+            }
+            s0 = s1;
+          }
           touched.clear();
-          for (int q = 0; q < d.n_pairs; ++q) {
-            const int kq = (int)dest_of_pair(pairs[d.pair_begin + q]);
-            key[q] = kq;
-            if (count[kq]++ == 0) touched.push_back(kq);
+          for (int i = 0; i < d.n_obs; ++i) {
+            if (lane_slot[i] < 0) continue;
+            for (int j = i; j < lm_end[i]; ++j) {
+              if (lane_slot[j] < 0) continue;
+              const int kq = (int)(row_base[i] + lane_slot[j]);
+              if (count[kq]++ == 0) touched.push_back(kq);
+            }
           }
           int run = 0;
           for (int kq : touched) {
@@ -509,10 +548,18 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
             count[kq] = run;
             run += c;
           }
-          for (int q = 0; q < d.n_pairs; ++q) out[count[key[q]]++] = pairs[d.pair_begin + q];
+          unsigned short* out = pairs.data() + d.pair_begin;
+          for (int i = 0; i < d.n_obs; ++i) {
+            if (lane_slot[i] < 0) continue;
+            for (int j = i; j < lm_end[i]; ++j) {
+              if (lane_slot[j] < 0) continue;
+              out[count[(int)(row_base[i] + lane_slot[j])]++] = (unsigned short)(i | (j << 8));
+            }
+          }
           for (int kq : touched) count[kq] = 0;
-          std::copy(out.begin(), out.end(), pairs.begin() + d.pair_begin);
         } else {
+          generate_pairs(d);
+          auto dest_of_pair = [&](unsigned short pr) { return tri_index(lane_slot[pr & 0xff], lane_slot[pr >> 8], ncam); };
           keyed.resize(d.n_pairs);
           for (int q = 0; q < d.n_pairs; ++q) keyed[q] = {dest_of_pair(pairs[d.pair_begin + q]), pairs[d.pair_begin + q]};
           std::sort(keyed.begin(), keyed.end());
