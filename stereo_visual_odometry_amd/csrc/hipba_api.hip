@@ -833,12 +833,14 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
   HIPBA_HIP(launch_make_scale_c(P, lm.jacobi_scaling, s));
   HIPBA_HIP(launch_point_colnorm(P, lm, s));
 
+  // small windows: the control kernel of a pass zeroes S for the next one (see k_window_control)
+  const bool control_zeroes_S = small && !sharded && !direct;
   int iterations_run = 0;
   for (int iter = 1; iter <= std::max(lm.max_num_iterations, 0); ++iter) {
     // S is zeroed first so that, unsharded, the camera-block launch can initialise the reduced system too
     if (direct) {
       if (!R->S_fully_written) HIPBA_HIP(big_zero_lower(P, R->big, s));
-    } else if (R->S_doubles && !(R->S_fully_written && !sharded)) {
+    } else if (R->S_doubles && !(R->S_fully_written && !sharded) && !(control_zeroes_S && iter > 1)) {
       HIPBA_HIP(hipMemsetAsync(P.S, 0, sizeof(double) * (size_t)R->S_doubles, s));
     }
     const bool fuse_init = iter > 1 && !sharded;
@@ -873,12 +875,12 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
     if (!(small && !sharded)) HIPBA_HIP(launch_pose_update(P, s));
     HIPBA_HIP(launch_cost(P, lm, 0, n_act_blk, 1, 0, true, s));
     if (sharded) {
-      HIPBA_HIP(launch_window_control(P, lm, kReduce, nullptr, s));
+      HIPBA_HIP(launch_window_control(P, lm, kReduce, nullptr, 0, s));
       AR(P.wsum, 5, HIPBA_REDUCE_SUM);
-      HIPBA_HIP(launch_window_control(P, lm, kDecide, nullptr, s));
+      HIPBA_HIP(launch_window_control(P, lm, kDecide, nullptr, 0, s));
     } else {
       // a single window reports "still active" itself; batches are counted by k_count_active below
-      HIPBA_HIP(launch_window_control(P, lm, kFused, P.n_windows == 1 ? R->d_count + (iter & 3) : nullptr, s));
+      HIPBA_HIP(launch_window_control(P, lm, kFused, P.n_windows == 1 ? R->d_count + (iter & 3) : nullptr, control_zeroes_S ? 1 : 0, s));
     }
     iterations_run = iter;
     // "windows still active" travels to the host through a ring of pinned words.  Small windows: the host looks

@@ -23,7 +23,7 @@ hipError_t launch_window_gradient(const DevP& P, const LmParams& lm, int mode, h
 hipError_t launch_backsub(const DevP& P, const LmParams& lm, hipStream_t s);
 hipError_t launch_pose_update(const DevP& P, hipStream_t s);
 hipError_t launch_window_init(const DevP& P, const LmParams& lm, int mode, hipStream_t s);
-hipError_t launch_window_control(const DevP& P, const LmParams& lm, int mode, int* count_out, hipStream_t s);
+hipError_t launch_window_control(const DevP& P, const LmParams& lm, int mode, int* count_out, int zero_S, hipStream_t s);
 hipError_t launch_count_active(const DevP& P, int* out, hipStream_t s);
 hipError_t launch_residual_jacobian(const CameraK& K, const LmParams& lm, int apply_loss, long long n_obs,
                                     const double* poses, const double* points, const int* obs_pose,

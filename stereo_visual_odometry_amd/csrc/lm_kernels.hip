@@ -1254,9 +1254,19 @@ __device__ __forceinline__ void window_control_body(const DevP& P, const LmParam
 
 // count_out (one-window solves): the "windows still active" word the host polls, written here instead of by a
 // launch of k_count_active
-__global__ __launch_bounds__(kBlock) void k_window_control(DevP P, LmParams lm, int mode, int* count_out) {
+// zero_S: a window that goes on to another iteration has its packed reduced matrix zeroed here, so the host does
+// not queue a memset (a launch of its own on the iteration's critical path) before every pass
+__global__ __launch_bounds__(kBlock) void k_window_control(DevP P, LmParams lm, int mode, int* count_out, int zero_S) {
   window_control_body(P, lm, mode);
   if (count_out && threadIdx.x == 0) *count_out = P.ws[blockIdx.x].active ? 1 : 0;
+  if (!zero_S) return;
+  __syncthreads();  // the decision thread 0 has just written
+  const WinState* st = P.ws + blockIdx.x;
+  if (!*reinterpret_cast<const volatile int*>(&st->active)) return;
+  const WinDesc wd = P.wd[blockIdx.x];
+  double2* Sw = reinterpret_cast<double2*>(P.S + wd.S_off);
+  const long long n2 = 18ll * ((long long)wd.ncam * (wd.ncam + 1) / 2);
+  for (long long i = threadIdx.x; i < n2; i += kBlock) Sw[i] = make_double2(0.0, 0.0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1745,8 +1755,8 @@ hipError_t launch_window_init(const DevP& P, const LmParams& lm, int mode, hipSt
   return hipGetLastError();
 }
 
-hipError_t launch_window_control(const DevP& P, const LmParams& lm, int mode, int* count_out, hipStream_t s) {
-  hipLaunchKernelGGL(k_window_control, dim3(P.n_windows), dim3(kBlock), 0, s, P, lm, mode, count_out);
+hipError_t launch_window_control(const DevP& P, const LmParams& lm, int mode, int* count_out, int zero_S, hipStream_t s) {
+  hipLaunchKernelGGL(k_window_control, dim3(P.n_windows), dim3(kBlock), 0, s, P, lm, mode, count_out, zero_S);
   return hipGetLastError();
 }
 
