@@ -1336,6 +1336,45 @@ __device__ __forceinline__ bool factor_invert_6x6(double* D) {
   return ok;
 }
 
+// The same for a whole wave (all 64 lanes call it): lane r < 6 carries row r of the lower factor L = R^T, the pivots
+// and multipliers travel as wave-uniform scalars, and lanes 16-21 start from the columns of the identity and execute
+// the very same scalings and multiply-subtracts, which leaves column r of L^-1 (= row r of R^-1) in lane 16 + r:
+// the inverse costs no instruction of its own and the dependency chain is one column per step, not one term.
+__device__ __forceinline__ bool factor_invert_6x6_wave(double* D, int lane) {
+  const int r = lane & 15;
+  const bool inverse_half = (lane & 16) != 0;
+  const bool row_lane = r < 6;
+  double x[6];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    // row r of L starts as row r of the symmetric block, read from the upper triangle: D(r, c) = D(c, r), c <= r
+    const double a = (row_lane && c <= r) ? D[6 * c + r] : 0.0;
+    x[c] = inverse_half ? (c == r ? 1.0 : 0.0) : a;
+  }
+  bool ok = true;
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x[c]), c), hi = __builtin_amdgcn_readlane(__double2hiint(x[c]), c);
+    const double d = __hiloint2double(hi, lo);
+    if (!(d > 0.0) || !isfinite(d)) ok = false;
+    double inv = __builtin_amdgcn_rsq(d);
+    inv = inv * (1.5 - 0.5 * d * inv * inv);
+    inv = inv * (1.5 - 0.5 * d * inv * inv);
+    x[c] *= inv;
+#pragma unroll
+    for (int kc = c + 1; kc < 6; ++kc) {
+      const int mlo = __builtin_amdgcn_readlane(__double2loint(x[c]), kc), mhi = __builtin_amdgcn_readlane(__double2hiint(x[c]), kc);
+      x[kc] -= x[c] * __hiloint2double(mhi, mlo);  // L(kc, c)
+    }
+  }
+  if (ok && inverse_half && row_lane && lane < 32) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+      if (i >= r) D[6 * r + i] = x[i];  // R^-1(r, i) = L^-1(i, r)
+  }
+  return ok;
+}
+
 // fuse_pose_update: the workgroup goes on to form the window's candidate poses (k_pose_update's work) from the
 // solution it has just written: one launch less per iteration.
 __global__ __launch_bounds__(kSolveThreads) void k_window_solve_small(DevP P, LmParams lm, int fuse_pose_update) {
@@ -1415,25 +1454,26 @@ __global__ __launch_bounds__(kSolveThreads) void k_window_solve_small(DevP P, Lm
     // consecutive blocks; the last m items update the right-hand side.
     const int npair = m * (m + 1) / 2;
     const int nitem = 2 * npair + m;
-    if (t == 0) {
+    if (t < 64) {
+      // wave 0: the next diagonal block, the critical path of the step -- issued first.  36 lanes take one entry of
+      // the rank-6 update each (the upper triangle is the one kept), then the wave factors and inverts the block
+      // with a lane per row (factor_invert_6x6_wave).  The rest of the wave's time is idle on purpose: update items
+      // here would run after this chain, not beside it.
       if (m > 0) {
-        __builtin_amdgcn_s_setprio(3);  // the chain below is the critical path of the step: issue it first
+        __builtin_amdgcn_s_setprio(3);
         const double* Ri = Rm + (rowk + 1) * kSmallBlk;
         double* T = Rm + (int)tri_index(k + 1, k + 1, nb) * kSmallBlk;
-        double ri[36];
+        const int a = t / 6, c = t - 6 * a;
+        if (t < 36 && a <= c) {
+          double v = T[6 * a + c];
 #pragma unroll
-        for (int i = 0; i < 36; ++i) ri[i] = Ri[i];
-#pragma unroll
-        for (int a = 0; a < 6; ++a) {
-#pragma unroll
-          for (int c = a; c < 6; ++c) {
-            double v = T[6 * a + c];
-#pragma unroll
-            for (int mm = 0; mm < 6; ++mm) v -= ri[6 * mm + a] * ri[6 * mm + c];
-            T[6 * a + c] = v;
-          }
+          for (int mm = 0; mm < 6; ++mm) v -= Ri[6 * mm + a] * Ri[6 * mm + c];
+          T[6 * a + c] = v;
         }
-        if (!factor_invert_6x6(T)) fail = 1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (!factor_invert_6x6_wave(T, t) && t == 0) fail = 1;
         __builtin_amdgcn_s_setprio(0);
       }
     } else if (t >= 64) {
