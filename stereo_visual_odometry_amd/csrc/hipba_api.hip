@@ -909,7 +909,13 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
   const size_t ws_bytes = rup256(sizeof(WinState) * (size_t)P.n_windows);
   const size_t pose_bytes = rup256(sizeof(double) * 7 * (size_t)P.n_poses), point_bytes = rup256(sizeof(double) * 3 * (size_t)P.n_pm_points);
   const size_t tail_bytes = ws_bytes + 2 * (pose_bytes + point_bytes);
-  if (fetch_tail && tail_bytes <= ((size_t)1 << 20) && ensure_staging(h, tail_bytes) == HIPBA_OK) {
+  bool tail = fetch_tail && tail_bytes <= ((size_t)1 << 20);
+  if (tail && h->staging_bytes < tail_bytes) {
+    // the staging buffer has to grow: nothing queued may still be reading the old one (the upload came from it)
+    HIPBA_HIP(hipStreamSynchronize(s));
+    tail = ensure_staging(h, tail_bytes) == HIPBA_OK;
+  }
+  if (tail) {
     // one round trip instead of three: everything the caller will read travels behind the last kernel
     char* st = static_cast<char*>(h->staging);
     HIPBA_HIP(hipMemcpyAsync(st, P.ws, sizeof(WinState) * P.n_windows, hipMemcpyDeviceToHost, s));

@@ -210,6 +210,18 @@ def test_edge_cases(solver, oracle):
     s = solver.solve(q, hipba.default_options(max_num_iterations=0))
     assert s["termination_type"] == hipba.NO_CONVERGENCE and s["num_iterations"] == 1
     np.testing.assert_array_equal(q.poses, p.poses)
+    # many unobserved landmarks, few observations, a fresh handle and no iteration at all: what comes back is larger
+    # than what went up was staged for; unobserved blocks are returned untouched
+    fresh = hipba.Solver(0)
+    big_pts = np.concatenate([p.points, np.random.default_rng(7).normal(size=(20000, 3)) + [0, 0, 30.0]])
+    u = hipba.Problem(p.poses.copy(), big_pts.copy(), p.obs_pose, p.obs_point, p.obs_uv, K)
+    s = fresh.solve(u, hipba.default_options(max_num_iterations=0))
+    assert s["termination_type"] == hipba.NO_CONVERGENCE
+    np.testing.assert_array_equal(u.points, big_pts); np.testing.assert_array_equal(u.poses, p.poses)
+    s = fresh.solve(u, hipba.reference_production_options())
+    assert s["termination_type"] == hipba.CONVERGENCE and s["final_cost"] < s["initial_cost"]
+    np.testing.assert_array_equal(u.points[p.points.shape[0]:], big_pts[p.points.shape[0]:])
+    fresh.close()
     # duplicate observation of one landmark by one pose is a legal pair of residual blocks
     d = p.copy()
     d2 = hipba.Problem(d.poses, d.points, np.concatenate([d.obs_pose, d.obs_pose[-3:]]),
