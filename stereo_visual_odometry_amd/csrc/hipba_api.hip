@@ -13,7 +13,10 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <numeric>
 #include <string>
 #include <thread>
@@ -53,8 +56,67 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace
 
+// A few host threads kept by a handle for the analysis of small windows: that analysis takes a few hundred
+// microseconds, of which starting and joining fresh threads was a quarter.  run(n, f) calls f(0) .. f(n - 1), f(0) on
+// the caller; the workers sleep on a condition variable in between.
+class HostWorkers {
+ public:
+  ~HostWorkers() {
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      stop_ = true;
+    }
+    go_.notify_all();
+    for (auto& t : threads_) t.join();
+  }
+  void run(int n, const std::function<void(int)>& f) {
+    if (n <= 1) { if (n == 1) f(0); return; }
+    while ((int)threads_.size() < n - 1) {
+      const int id = (int)threads_.size() + 1;
+      threads_.emplace_back([this, id] { loop(id); });
+    }
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      job_ = &f; parts_ = n; pending_ = n - 1; ++generation_;
+    }
+    go_.notify_all();
+    f(0);
+    std::unique_lock<std::mutex> lk(m_);
+    done_.wait(lk, [this] { return pending_ == 0; });
+    job_ = nullptr;
+  }
+
+ private:
+  void loop(int id) {
+    long long seen = 0;
+    for (;;) {
+      const std::function<void(int)>* job = nullptr;
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        go_.wait(lk, [&] { return stop_ || generation_ != seen; });
+        if (stop_) return;
+        seen = generation_;
+        if (id < parts_) job = job_;
+      }
+      if (job) {
+        (*job)(id);
+        std::lock_guard<std::mutex> lk(m_);
+        if (--pending_ == 0) done_.notify_one();
+      }
+    }
+  }
+  std::vector<std::thread> threads_;
+  std::mutex m_;
+  std::condition_variable go_, done_;
+  const std::function<void(int)>* job_ = nullptr;
+  int parts_ = 0, pending_ = 0;
+  long long generation_ = 0;
+  bool stop_ = false;
+};
+
 struct hipba_handle_s {
   int device = 0;
+  HostWorkers workers;
   hipStream_t stream = nullptr;
   // grow-only buffers reused by hipba_solve / hipba_solve_batched
   void* arena = nullptr;
@@ -577,6 +639,8 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
     auto lo = [&](int i) { return (int)((long long)n_blk_pm * i / n_thr); };
     if (n_thr <= 1) {
       group_range(0, 0, n_blk_pm);
+    } else if (n_thr <= 4) {
+      h->workers.run(n_thr, [&](int i) { group_range(i, lo(i), lo(i + 1)); });  // the handle's sleeping workers
     } else {
       std::vector<std::thread> pool;
       for (int i = 0; i < n_thr; ++i) pool.emplace_back(group_range, i, lo(i), lo(i + 1));
