@@ -552,7 +552,7 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
     // a keyframe window has ~10^5 pairs: worth four short-lived threads (grouping them is the longest host step
     // of hipba_solve); large problems use up to sixteen
     const int n_thr = (int)std::min<size_t>(std::max(1u, std::min(16u, std::thread::hardware_concurrency())),
-                                            pairs.size() < 1000000 ? std::min<size_t>(4, 1 + pairs.size() / 20000)
+                                            pairs.size() < 1000000 ? std::min<size_t>(8, 1 + pairs.size() / 12000)
                                                                    : 1 + pairs.size() / 1000000);
     std::vector<std::vector<RunDesc>> runs_of(n_thr);
     std::vector<std::vector<int>> nruns_of(n_thr);
@@ -639,7 +639,7 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
     auto lo = [&](int i) { return (int)((long long)n_blk_pm * i / n_thr); };
     if (n_thr <= 1) {
       group_range(0, 0, n_blk_pm);
-    } else if (n_thr <= 4) {
+    } else if (n_thr <= 8) {
       h->workers.run(n_thr, [&](int i) { group_range(i, lo(i), lo(i + 1)); });  // the handle's sleeping workers
     } else {
       std::vector<std::thread> pool;
