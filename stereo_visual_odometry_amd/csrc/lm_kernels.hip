@@ -519,16 +519,18 @@ __global__ __launch_bounds__(kBlock) void k_point_schur(DevP P, LmParams lm, int
     // the block's pair and run lists go to LDS when they fit; the loads are issued here, ahead of the
     // observation work, and land in LDS together with Y and W
     const bool lists_in_lds = MODE != 2 && d.n_pairs <= kLdsPairs && d.n_runs <= kLdsRuns;
-    uint4 pv[2] = {}, rv[2] = {};
+    // (native vector types, named one by one: an array of HIP's uint4 class is not promoted to registers -- it sat in
+    // scratch, and every one of these loads waited for its own round trip to memory before the next was issued)
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+    v4u pv0 = {0, 0, 0, 0}, pv1 = {0, 0, 0, 0}, rv0 = {0, 0, 0, 0}, rv1 = {0, 0, 0, 0};
     if (lists_in_lds) {
-      const uint4* gp = reinterpret_cast<const uint4*>(P.pairs + d.pair_begin);
-      const uint4* gr = reinterpret_cast<const uint4*>(P.runs + d.run_begin);
+      const v4u* gp = reinterpret_cast<const v4u*>(P.pairs + d.pair_begin);
+      const v4u* gr = reinterpret_cast<const v4u*>(P.runs + d.run_begin);
       const int npv = (d.n_pairs + 7) >> 3, nrv = (d.n_runs + 1) >> 1;
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        if (t + m * kBlock < npv) pv[m] = gp[t + m * kBlock];
-        if (t + m * kBlock < nrv) rv[m] = gr[t + m * kBlock];
-      }
+      if (t < npv) pv0 = gp[t];
+      if (t + kBlock < npv) pv1 = gp[t + kBlock];
+      if (t < nrv) rv0 = gr[t];
+      if (t + kBlock < nrv) rv1 = gr[t + kBlock];
     }
     double r[2], Jc[12], Jp[6];
     int pp = -1, slot = -1;
@@ -629,11 +631,10 @@ __global__ __launch_bounds__(kBlock) void k_point_schur(DevP P, LmParams lm, int
     __syncthreads();  // every lane has finished reading the phase-1 words
     HIPBA_TICK(3);
     if (lists_in_lds) {
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        reinterpret_cast<uint4*>(sPairs)[t + m * kBlock] = pv[m];
-        reinterpret_cast<uint4*>(sRuns)[t + m * kBlock] = rv[m];
-      }
+      reinterpret_cast<v4u*>(sPairs)[t] = pv0;
+      reinterpret_cast<v4u*>(sPairs)[t + kBlock] = pv1;
+      reinterpret_cast<v4u*>(sRuns)[t] = rv0;
+      reinterpret_cast<v4u*>(sRuns)[t + kBlock] = rv1;
     }
     if (MODE != 2 && live) {
       sslot[t] = slot;
