@@ -386,9 +386,20 @@ __global__ __launch_bounds__(kBlock) void k_point_colnorm(DevP P, LmParams lm) {
 __device__ unsigned long long g_ticks[8 * 4096];
 #endif
 
+// 1/sqrt(x): hardware estimate + two Newton steps (full double precision, no division)
+__device__ __forceinline__ double rsqrt_newton(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  r = r * (1.5 - 0.5 * x * r * r);
+  r = r * (1.5 - 0.5 * x * r * r);
+  return r;
+}
+
 constexpr int kPairGroup = 12;
 constexpr int kPairGroups = kBlock / kPairGroup;  // 21
-constexpr int kYW = 37;  // LDS doubles per lane for Y (18) and W (18); odd, so lanes fall on different banks
+// LDS doubles per lane for Z = W C (6x3), C the lower Cholesky factor of V^-1: Y_i W_j^T = W_i V^-1 W_j^T = Z_i Z_j^T,
+// so one 18-word factor per observation serves both sides of a product (half the staging of Y and W, which is what
+// lets two workgroups share a CU); odd, so lanes fall on different banks
+constexpr int kYW = 19;
 
 // Pair products of one block: a lane group takes whole runs (same destination), sums each in registers
 // and adds it to the reduced matrix once.  WIDE: twelve lanes per product, three outputs each, the three
@@ -413,7 +424,7 @@ __device__ __forceinline__ void pair_products(const unsigned short* pairs, const
         if (q < cnt) {
           const int i = pr[q] & 0xff, j = pr[q] >> 8;
           const double* Yi = sYW + kYW * i;
-          const double* Wj = sYW + kYW * j + 18 + 3 * bcol;
+          const double* Wj = sYW + kYW * j + 3 * bcol;
           const double w0 = Wj[0], w1 = Wj[1], w2 = Wj[2];
 #pragma unroll
           for (int m = 0; m < 3; ++m) {
@@ -442,7 +453,7 @@ __device__ __forceinline__ void pair_products(const unsigned short* pairs, const
         if (q < cnt) {
           const int i = pr[q] & 0xff, j = pr[q] >> 8;
           const double* Yi = sYW + kYW * i;
-          const double* Wj = sYW + kYW * j + 18 + 9 * h;
+          const double* Wj = sYW + kYW * j + 9 * h;
           double wj[9];
 #pragma unroll
           for (int ii = 0; ii < 9; ++ii) wj[ii] = Wj[ii];
@@ -478,7 +489,7 @@ __global__ __launch_bounds__(kBlock) void k_point_schur(DevP P, LmParams lm, int
   constexpr bool LDS_S = MODE == 1;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int kStage = MODE == 2 ? 9 : kYW;  // gathered mode stages only the phase-1 words
-  double* sYW = smem;                         // [kBlock][kYW]: Y (18) then W (18); phase 1 aliases 9 words/lane
+  double* sYW = smem;                         // [kBlock][kYW]: Z (18 words); phase 1 aliases 9 words/lane
   int* sslot = reinterpret_cast<int*>(smem + kBlock * kStage);  // [kBlock] local slot or -1
   double* red = smem + kBlock * kStage + kBlock / 2;            // [8]
   unsigned short* sPairs = reinterpret_cast<unsigned short*>(red + 8);   // [kLdsPairs] (not in staged mode)
@@ -562,7 +573,7 @@ __global__ __launch_bounds__(kBlock) void k_point_schur(DevP P, LmParams lm, int
     __syncthreads();
     HIPBA_TICK(2);
 
-    double Y[18], W[18];
+    double Z[18];
     if (live) {
       const int s0 = (int)(P.pp_obs_start[pp] - d.obs_begin);
       const int s1 = (int)(P.pp_obs_start[pp + 1] - d.obs_begin);
@@ -606,23 +617,33 @@ __global__ __launch_bounds__(kBlock) void k_point_schur(DevP P, LmParams lm, int
         }
       }
       if (MODE != 2 && slot >= 0) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-#pragma unroll
-          for (int j = 0; j < 3; ++j) W[3 * i + j] = Jc[i] * Jp[j] + Jc[6 + i] * Jp[3 + j];
+        // V^-1 = C C^T (C lower triangular; V^-1 is positive definite with V), Z = W C with W = Jc^T Jp
+        double c00, c10, c20, c11, c21, c22;
+        {
+          const double r0 = rsqrt_newton(Vi[0]);
+          c00 = Vi[0] * r0; c10 = Vi[1] * r0; c20 = Vi[2] * r0;
+          const double d1 = Vi[3] - c10 * c10;
+          const double r1 = rsqrt_newton(d1);
+          c11 = d1 * r1; c21 = (Vi[4] - c20 * c10) * r1;
+          const double d2 = Vi[5] - c20 * c20 - c21 * c21;
+          c22 = d2 * rsqrt_newton(d2);
         }
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-          Y[3 * i + 0] = W[3 * i] * Vi[0] + W[3 * i + 1] * Vi[1] + W[3 * i + 2] * Vi[2];
-          Y[3 * i + 1] = W[3 * i] * Vi[1] + W[3 * i + 1] * Vi[3] + W[3 * i + 2] * Vi[4];
-          Y[3 * i + 2] = W[3 * i] * Vi[2] + W[3 * i + 1] * Vi[4] + W[3 * i + 2] * Vi[5];
+          const double w0 = Jc[i] * Jp[0] + Jc[6 + i] * Jp[3];
+          const double w1 = Jc[i] * Jp[1] + Jc[6 + i] * Jp[4];
+          const double w2 = Jc[i] * Jp[2] + Jc[6 + i] * Jp[5];
+          Z[3 * i + 0] = w0 * c00 + w1 * c10 + w2 * c20;
+          Z[3 * i + 1] = w1 * c11 + w2 * c21;
+          Z[3 * i + 2] = w2 * c22;
         }
-        // b_c -= Y g_p (gathered mode leaves this to k_camera_rhs: one writer per pose instead of atomics)
+        // b_c -= Y g_p = Z (C^T g_p) (gathered mode leaves this to k_camera_rhs: one writer per pose instead of atomics)
         if (MODE != 2) {
+          const double u0 = c00 * gpv[0] + c10 * gpv[1] + c20 * gpv[2], u1 = c11 * gpv[1] + c21 * gpv[2], u2 = c22 * gpv[2];
           double* bdst = SMALL ? accB + 6 * slot : P.b + 6ll * (wd.cam_base + slot);
 #pragma unroll
           for (int i = 0; i < 6; ++i) {
-            const double v = Y[3 * i] * gpv[0] + Y[3 * i + 1] * gpv[1] + Y[3 * i + 2] * gpv[2];
+            const double v = Z[3 * i] * u0 + Z[3 * i + 1] * u1 + Z[3 * i + 2] * u2;
             atomic_add_f64(bdst + i, -v);
           }
         }
@@ -639,9 +660,9 @@ __global__ __launch_bounds__(kBlock) void k_point_schur(DevP P, LmParams lm, int
     if (MODE != 2 && live) {
       sslot[t] = slot;
       if (slot >= 0) {
-        double* yw = sYW + kYW * t;
+        double* z = sYW + kYW * t;
 #pragma unroll
-        for (int i = 0; i < 18; ++i) { yw[i] = Y[i]; yw[18 + i] = W[i]; }
+        for (int i = 0; i < 18; ++i) z[i] = Z[i];
       }
     }
     __syncthreads();
