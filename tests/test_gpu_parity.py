@@ -382,6 +382,28 @@ def test_staged_schur_accumulation_matches_oracle(solver, oracle, loss):
     assert np.abs(g.poses - g2.poses).max() <= 1e-11
 
 
+def test_gathered_elimination_when_every_camera_pair_shares_a_landmark(solver, oracle):
+    """25 cameras that all see each other: every block of the reduced matrix has a pair, so the gather's stores
+    (straight into the dense factorisation's matrix) are the only initialisation its off-diagonal blocks get."""
+    prob, _, _ = scenes.bal_scale(seed=29, grid=(5, 5), n_points=70000, depth_lo=20.0, depth_hi=80.0)  # ~2.3M pairs: gathered mode
+    pairs = set()
+    order = np.lexsort((prob.obs_pose, prob.obs_point))
+    op, oq = prob.obs_pose[order], prob.obs_point[order]
+    for k in range(0, len(op) - 7, 8):  # eight observations per landmark
+        assert len(set(oq[k:k + 8])) == 1
+        cams = [c for c in op[k:k + 8] if c != 0]
+        pairs.update((a, b) for a in cams for b in cams if a < b)
+    assert len(pairs) == 24 * 23 // 2
+    g = prob.copy()
+    s = solver.solve(g, hipba.default_options(max_num_iterations=5))
+    o = to_oracle(oracle, prob)
+    so, oits = oracle.solve(o, oracle.default_options(max_num_iterations=5, jacobian_mode=oracle.JAC_ANALYTIC, num_threads=8))
+    assert s["termination_type"] == so["termination_type"]
+    assert abs(s["final_cost"] - so["final_cost"]) <= RTOL_COST * so["final_cost"]
+    assert np.abs(g.poses - o.poses).max() <= ATOL_STATE and np.abs(g.points - o.points).max() <= ATOL_STATE
+    assert_logs_match(s["iterations"], oits)
+
+
 def test_gathered_elimination_with_constant_poses_and_landmarks(solver, oracle):
     """The per-block gather next to every observation class: constant poses (their observations feed V and g_p but
     no block of S), constant landmarks seen by variable poses (camera blocks only) and by constant poses (fixed
