@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -69,8 +70,10 @@ class HostWorkers {
     go_.notify_all();
     for (auto& t : threads_) t.join();
   }
-  void run(int n, const std::function<void(int)>& f) {
-    if (n <= 1) { if (n == 1) f(0); return; }
+  // returns false if a part threw (out of memory): the exception stays inside its thread
+  bool run(int n, const std::function<void(int)>& f) {
+    failed_ = false;
+    if (n <= 1) { if (n == 1) call(f, 0); return !failed_; }
     while ((int)threads_.size() < n - 1) {
       const int id = (int)threads_.size() + 1;
       threads_.emplace_back([this, id] { loop(id); });
@@ -80,13 +83,17 @@ class HostWorkers {
       job_ = &f; parts_ = n; pending_ = n - 1; ++generation_;
     }
     go_.notify_all();
-    f(0);
+    call(f, 0);
     std::unique_lock<std::mutex> lk(m_);
     done_.wait(lk, [this] { return pending_ == 0; });
     job_ = nullptr;
+    return !failed_;
   }
 
  private:
+  void call(const std::function<void(int)>& f, int i) {
+    try { f(i); } catch (...) { failed_ = true; }
+  }
   void loop(int id) {
     long long seen = 0;
     for (;;) {
@@ -99,7 +106,7 @@ class HostWorkers {
         if (id < parts_) job = job_;
       }
       if (job) {
-        (*job)(id);
+        call(*job, id);
         std::lock_guard<std::mutex> lk(m_);
         if (--pending_ == 0) done_.notify_one();
       }
@@ -112,6 +119,7 @@ class HostWorkers {
   int parts_ = 0, pending_ = 0;
   long long generation_ = 0;
   bool stop_ = false;
+  std::atomic<bool> failed_{false};
 };
 
 struct hipba_handle_s {
@@ -640,7 +648,11 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
     if (n_thr <= 1) {
       group_range(0, 0, n_blk_pm);
     } else if (n_thr <= 8) {
-      h->workers.run(n_thr, [&](int i) { group_range(i, lo(i), lo(i + 1)); });  // the handle's sleeping workers
+      // the handle's sleeping workers
+      if (!h->workers.run(n_thr, [&](int i) { group_range(i, lo(i), lo(i + 1)); })) {
+        delete R;
+        return fail(HIPBA_ERR_OUT_OF_MEMORY, "host analysis of the pair lists ran out of memory");
+      }
     } else {
       std::vector<std::thread> pool;
       for (int i = 0; i < n_thr; ++i) pool.emplace_back(group_range, i, lo(i), lo(i + 1));
