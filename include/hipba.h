@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 /* bumped whenever a struct of this header changes size or layout; hipba_version() returns the library's value */
-#define HIPBA_VERSION 101
+#define HIPBA_VERSION 102
 
 /* status codes */
 enum {
@@ -41,7 +41,8 @@ enum {
   HIPBA_ERR_HIP = -3,              /* a HIP runtime call failed */
   HIPBA_ERR_OUT_OF_MEMORY = -4,
   HIPBA_ERR_UNSUPPORTED = -5,      /* e.g. a landmark with more than HIPBA_MAX_POINT_DEGREE observations */
-  HIPBA_ERR_COMM = -6              /* the caller's all-reduce callback failed */
+  HIPBA_ERR_COMM = -6,             /* the caller's all-reduce callback failed */
+  HIPBA_ERR_INTERNAL = -7          /* an unexpected C++ exception was caught at the boundary */
 };
 
 /* reference: optimizer.hpp:56-57 (z forward, production) vs test/ba_test.h:205-206 (x forward) */
@@ -98,6 +99,16 @@ typedef struct hipba_options {
   int32_t pcg_max_iterations;               /* 500 */
   double pcg_tolerance;                     /* 1e-12, relative residual |r|/|b| */
   int32_t minimizer_progress_to_stdout;     /* 0; 1 prints a Ceres-like table (optimizer.cpp:56) */
+  /* 0 (default): TrustRegionMinimizer::ParameterToleranceReached as upstream Ceres 2.0-2.2 has it -- the test
+     |step| <= parameter_tolerance * (|x| + parameter_tolerance) runs on every valid step, also the first one.
+     1: the test is skipped until one step has been accepted.  That is NOT an upstream Ceres rule; it is kept
+     only so that the difference can be measured (a window that starts converged runs on until the function
+     tolerance or the trust-region radius ends it). */
+  int32_t parameter_tolerance_needs_success;
+  /* 0; 1 brackets the phases of every iteration with HIP events and fills the time_*_evaluation_s /
+     time_linear_solver_s fields of the summary (the split ceres::Solver::Summary::FullReport prints,
+     optimizer.cpp:62); costs a few event records per iteration */
+  int32_t report_time_breakdown;
   int32_t reserved;
 } hipba_options;
 
@@ -142,6 +153,14 @@ typedef struct hipba_summary {
   /* bytes this call moved over the host link (for a batched call: the whole call, in every summary) */
   int64_t bytes_host_to_device;
   int64_t bytes_device_to_host;
+  /* FullReport's "Time (in seconds)" split, device time summed over the iterations; filled (else 0) when
+     options.report_time_breakdown is set.  Residual evaluation = the cost passes; Jacobian evaluation = the
+     camera-block pass (the landmark side of J is recomputed inside the elimination, which Ceres books under
+     its Schur linear solver as well); linear solver = landmark elimination + reduced solve + back-substitution
+     + retraction.  A batched call reports the whole batch in every summary. */
+  double time_residual_evaluation_s;
+  double time_jacobian_evaluation_s;
+  double time_linear_solver_s;
 } hipba_summary;
 
 typedef struct hipba_handle_s* hipba_handle;          /* one per calling thread and GPU */

@@ -843,7 +843,7 @@ void oracle_options_default(oracle_options* o) {
   o->linear_solver = ORACLE_LIN_AUTO;
   o->num_threads = 1;
   o->jacobi_scaling = 1;
-  o->param_tol_needs_success = 1;
+  o->param_tol_needs_success = 0;
   o->initial_trust_region_radius = 1e4;
   o->max_trust_region_radius = 1e16;
   o->min_trust_region_radius = 1e-32;

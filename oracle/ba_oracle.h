@@ -58,7 +58,8 @@ typedef struct {
   int32_t linear_solver;               /* ORACLE_LIN_* */
   int32_t num_threads;                 /* OpenMP threads for evaluation */
   int32_t jacobi_scaling;              /* 1 */
-  int32_t param_tol_needs_success;     /* 1 = Ceres 2.2 rule (tolerance only after one successful step) */
+  int32_t param_tol_needs_success;     /* 0: upstream TrustRegionMinimizer::ParameterToleranceReached (tested on every
+                                          valid step); 1: only after one accepted step (not an upstream rule) */
   double initial_trust_region_radius;  /* 1e4 */
   double max_trust_region_radius;      /* 1e16 */
   double min_trust_region_radius;      /* 1e-32 */

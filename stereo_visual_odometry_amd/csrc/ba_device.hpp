@@ -97,6 +97,7 @@ struct LmParams {
   double min_lm_diagonal, max_lm_diagonal;
   double function_tolerance, gradient_tolerance, parameter_tolerance;
   double initial_radius;
+  int param_tol_needs_success;  // hipba_options::parameter_tolerance_needs_success
 };
 
 struct DevP {

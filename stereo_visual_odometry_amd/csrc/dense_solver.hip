@@ -771,23 +771,29 @@ __global__ void k_store_solution(DevP P, const double* y, int n) {
   if (!isfinite(v)) P.ws[0].solve_failed = 1;
 }
 
+constexpr size_t kLdsTrsm = (size_t)(2 * KC * (kTrsmRows + 16) + 2 * KC * (NB + 16)) * 8;
+constexpr size_t kLdsK128 = (size_t)(4 * KC * (64 + 16)) * 8;
+constexpr size_t kLdsK128Fused = kLdsK128 > kPotrfLds ? kLdsK128 : kPotrfLds;
+constexpr size_t kLdsNtFused = kGemmNtLds > kPotrfLds ? kGemmNtLds : kPotrfLds;
+
+// Dynamic-LDS limits of the factorisation kernels.  The attribute belongs to the function ON THE CURRENT DEVICE:
+// called by hipba_create for every handle, with the handle's device current.
+hipError_t configure_dense_kernels() {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_potrf_inv),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPotrfLds);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_k128<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)kLdsK128Fused);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_k128<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)kLdsTrsm);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_nt<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)kLdsNtFused);
+  return e;
+}
+
 hipError_t big_solve_cholesky(const DevP& P, const BigWork& W, hipStream_t s) {
-  constexpr size_t kLdsTrsm = (size_t)(2 * KC * (kTrsmRows + 16) + 2 * KC * (NB + 16)) * 8;
-  constexpr size_t kLdsK128 = (size_t)(4 * KC * (64 + 16)) * 8;
-  constexpr size_t kLdsK128Fused = kLdsK128 > kPotrfLds ? kLdsK128 : kPotrfLds;
-  constexpr size_t kLdsNtFused = kGemmNtLds > kPotrfLds ? kGemmNtLds : kPotrfLds;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_potrf_inv), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)kPotrfLds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_k128<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)kLdsK128Fused);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_k128<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)kLdsTrsm);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_nt<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)kLdsNtFused);
-    attr_done = true;
-  }
   const int n = W.n, npad = W.npad, nt = npad / NB;
   const int ld = (int)dense_ld(npad);  // one extra tile row: b^T rides along as row npad (see k_pad_init)
   const int ncam = n / 6;

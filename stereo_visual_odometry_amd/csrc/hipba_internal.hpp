@@ -10,6 +10,8 @@
 namespace hipba {
 
 // ---- kernel launch wrappers (lm_kernels.hip) ---------------------------------------------------
+hipError_t configure_lm_kernels();     // per device, from hipba_create
+hipError_t configure_dense_kernels();  // (dense_solver.hip)
 size_t schur_lds_bytes(int small_ncam, bool staged);
 hipError_t launch_cost(const DevP& P, const LmParams& lm, int blk_off, int n_blk, int which, int ignore_active,
                        bool second_bank, hipStream_t s);
@@ -26,7 +28,7 @@ hipError_t launch_window_init(const DevP& P, const LmParams& lm, int mode, hipSt
 hipError_t launch_window_control(const DevP& P, const LmParams& lm, int mode, int* count_out, int zero_S, hipStream_t s);
 hipError_t launch_count_active(const DevP& P, int* out, hipStream_t s);
 hipError_t launch_residual_jacobian(const CameraK& K, const LmParams& lm, int apply_loss, long long n_obs,
-                                    const double* poses, const double* points, const int* obs_pose,
+                                    int n_poses, int n_points, const double* poses, const double* points, const int* obs_pose,
                                     const int* obs_point, const double* obs_uv, double* res, double* jc, double* jp,
                                     double* cost_part, double* cost_out, hipStream_t s);
 

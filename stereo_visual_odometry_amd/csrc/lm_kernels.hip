@@ -1228,8 +1228,10 @@ __device__ __forceinline__ void window_control_body(const DevP& P, const LmParam
     it.step_norm = step_norm;
     double cand = acc[3];
     if (acc[4] > 0.0 || !isfinite(cand)) cand = DBL_MAX;
-    // ParameterToleranceReached (only after one successful step, as Ceres >= 2.2)
-    if (s.any_success && step_norm <= lm.parameter_tolerance * (x_norm + lm.parameter_tolerance)) {
+    // TrustRegionMinimizer::ParameterToleranceReached: on every valid step (the option delays it until a step
+    // has been accepted, which upstream Ceres does not do)
+    if ((s.any_success || !lm.param_tol_needs_success) &&
+        step_norm <= lm.parameter_tolerance * (x_norm + lm.parameter_tolerance)) {
       s.active = 0; s.termination = HIPBA_CONVERGENCE;
       *st = s;
       return;
@@ -1618,7 +1620,10 @@ __global__ __launch_bounds__(kBlock) void k_window_gradient(DevP P, LmParams lm,
 // ceres::Problem::Evaluate twin: one thread per observation, residual + Jacobians to HBM
 // (k_residual_jacobian of the design; also the kernel measured against the 184 B/obs figure)
 // ------------------------------------------------------------------------------------------
+// An observation whose pose or landmark index is out of range reads nothing and yields NaN outputs (and so a NaN
+// cost): callers that hand over device-resident index arrays cannot have them checked on the host.
 __global__ __launch_bounds__(kBlock) void k_residual_jacobian(CameraK K, LmParams lm, int apply_loss, long long n_obs,
+                                                              int n_poses, int n_points,
                                                               const double* __restrict__ poses,
                                                               const double* __restrict__ points,
                                                               const int* __restrict__ obs_pose,
@@ -1638,8 +1643,17 @@ __global__ __launch_bounds__(kBlock) void k_residual_jacobian(CameraK K, LmParam
     const double2 uv = reinterpret_cast<const double2*>(obs_uv)[o];
     LmParams l2 = lm;
     if (!apply_loss) l2.loss = HIPBA_LOSS_NONE;
-    c[0] = eval_obs<true>(K, l2, poses + 7ll * obs_pose[o], points + 3ll * obs_point[o], uv.x, uv.y, nullptr, nullptr,
-                          r, Jc, Jp);
+    const int ip = obs_pose[o], iq = obs_point[o];
+    if (ip >= 0 && ip < n_poses && iq >= 0 && iq < n_points) {
+      c[0] = eval_obs<true>(K, l2, poses + 7ll * ip, points + 3ll * iq, uv.x, uv.y, nullptr, nullptr, r, Jc, Jp);
+    } else {
+      const double bad = __builtin_nan("");
+      c[0] = r[0] = r[1] = bad;
+#pragma unroll
+      for (int i = 0; i < 12; ++i) Jc[i] = bad;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) Jp[i] = bad;
+    }
     if (res) reinterpret_cast<double2*>(res)[o] = make_double2(r[0], r[1]);
   }
   if (jac_pose) {
@@ -1709,6 +1723,22 @@ size_t schur_lds_bytes(int small_ncam, bool staged) {
   return base;
 }
 
+// Dynamic-LDS limits of the kernels that ask for more than the default 64 KB.  The attribute belongs to the function
+// ON THE CURRENT DEVICE: called by hipba_create for every handle, with the handle's device current.
+hipError_t configure_lm_kernels() {
+  const void* big[] = {reinterpret_cast<const void*>(&k_point_schur<0>), reinterpret_cast<const void*>(&k_point_schur<1>),
+                       reinterpret_cast<const void*>(&k_point_schur<2>), reinterpret_cast<const void*>(&k_point_schur<3>)};
+  for (const void* f : big) {
+    const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+  }
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_gather),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)((kBlock / 64) * kGatherLds * 8));
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_window_solve_small),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+}
+
 hipError_t launch_cost(const DevP& P, const LmParams& lm, int blk_off, int n_blk, int which, int ignore_active,
                        bool second_bank, hipStream_t s) {
   if (n_blk <= 0) return hipSuccess;
@@ -1744,27 +1774,9 @@ hipError_t launch_init_reduced(const DevP& P, const LmParams& lm, int owner, hip
 
 hipError_t launch_point_schur(const DevP& P, const LmParams& lm, int small_ncam, int parts, hipStream_t s) {
   if (P.n_blk_pm <= 0) return hipSuccess;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_point_schur<0>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_point_schur<1>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_point_schur<2>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_point_schur<3>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
-  }
   if (P.prec) {
     hipLaunchKernelGGL(k_point_schur<2>, dim3(P.n_blk_pm), dim3(kBlock), schur_lds_bytes(0, true), s, P, lm, 1);
-    static bool gather_attr_done = false;
     const size_t gather_lds = (size_t)(kBlock / 64) * kGatherLds * 8;
-    if (!gather_attr_done) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_gather),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)gather_lds);
-      gather_attr_done = true;
-    }
     const unsigned grid = (unsigned)((P.n_chunks + kBlock / 64 - 1) / (kBlock / 64));
     if (grid) hipLaunchKernelGGL(k_schur_gather, dim3(grid), dim3(kBlock), gather_lds, s, P, lm);
     hipLaunchKernelGGL(k_camera_rhs, dim3(P.n_act_poses), dim3(kBlock), 0, s, P, lm);
@@ -1783,12 +1795,6 @@ hipError_t launch_point_schur(const DevP& P, const LmParams& lm, int small_ncam,
 }
 
 hipError_t launch_window_solve_small(const DevP& P, const LmParams& lm, int max_n, int fuse_pose_update, hipStream_t s) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_window_solve_small),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-    attr_done = true;
-  }
   const size_t nb = (size_t)(max_n + 5) / 6;
   const size_t lds = (16 + nb * (nb + 1) / 2 * kSmallBlk + 6 * nb) * 8;
   hipLaunchKernelGGL(k_window_solve_small, dim3(P.n_windows), dim3(kSolveThreads), lds, s, P, lm, fuse_pose_update);
@@ -1828,13 +1834,13 @@ hipError_t launch_count_active(const DevP& P, int* out, hipStream_t s) {
 }
 
 hipError_t launch_residual_jacobian(const CameraK& K, const LmParams& lm, int apply_loss, long long n_obs,
-                                    const double* poses, const double* points, const int* obs_pose,
+                                    int n_poses, int n_points, const double* poses, const double* points, const int* obs_pose,
                                     const int* obs_point, const double* obs_uv, double* res, double* jc, double* jp,
                                     double* cost_part, double* cost_out, hipStream_t s) {
   if (n_obs <= 0) return hipSuccess;
   const long long nb = (n_obs + kBlock - 1) / kBlock;
-  hipLaunchKernelGGL(k_residual_jacobian, dim3((unsigned)nb), dim3(kBlock), 0, s, K, lm, apply_loss, n_obs, poses,
-                     points, obs_pose, obs_point, obs_uv, res, jc, jp, cost_part);
+  hipLaunchKernelGGL(k_residual_jacobian, dim3((unsigned)nb), dim3(kBlock), 0, s, K, lm, apply_loss, n_obs, n_poses,
+                     n_points, poses, points, obs_pose, obs_point, obs_uv, res, jc, jp, cost_part);
   if (cost_part && cost_out) hipLaunchKernelGGL(k_sum_serial, dim3(1), dim3(kBlock), 0, s, cost_part, nb, cost_out);
   return hipGetLastError();
 }

@@ -14,9 +14,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libhipba.so")
 
 OK = 0
-ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_OUT_OF_MEMORY, ERR_UNSUPPORTED, ERR_COMM = -1, -2, -3, -4, -5, -6
+ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_OUT_OF_MEMORY, ERR_UNSUPPORTED, ERR_COMM, ERR_INTERNAL = (
+    -1, -2, -3, -4, -5, -6, -7)
 CAMERA_Z_FORWARD, CAMERA_X_FORWARD = 0, 1
-ABI_VERSION = 101  # HIPBA_VERSION of the include/hipba.h these ctypes structures mirror
+ABI_VERSION = 102  # HIPBA_VERSION of the include/hipba.h these ctypes structures mirror
 LOSS_NONE, LOSS_HUBER = 0, 1
 LINEAR_AUTO, LINEAR_DENSE_CHOLESKY, LINEAR_PCG = 0, 1, 2
 CONVERGENCE, NO_CONVERGENCE, FAILURE = 0, 1, 2
@@ -51,7 +52,8 @@ class COptions(C.Structure):
         ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double),
         ("parameter_tolerance", C.c_double),
         ("pcg_max_iterations", C.c_int32), ("pcg_tolerance", C.c_double),
-        ("minimizer_progress_to_stdout", C.c_int32), ("reserved", C.c_int32),
+        ("minimizer_progress_to_stdout", C.c_int32), ("parameter_tolerance_needs_success", C.c_int32),
+        ("report_time_breakdown", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -76,6 +78,8 @@ class CSummary(C.Structure):
         ("linear_solver_used", C.c_int32), ("num_linear_solves", C.c_int32),
         ("iteration_log", C.POINTER(CIteration)), ("iteration_log_capacity", C.c_int32), ("reserved2", C.c_int32),
         ("bytes_host_to_device", C.c_int64), ("bytes_device_to_host", C.c_int64),
+        ("time_residual_evaluation_s", C.c_double), ("time_jacobian_evaluation_s", C.c_double),
+        ("time_linear_solver_s", C.c_double),
     ]
 
 

@@ -36,21 +36,29 @@ def to_oracle(p):
                           p.pose_const, p.point_const)
 
 
-def case(name, prob, loss, loss_scale, max_it):
+def case(name, prob, loss, loss_scale, max_it, **extra):
     o = to_oracle(prob)
     ev_a = oracle.evaluate(o, oracle.JAC_ANALYTIC, loss, loss_scale, apply_loss=True)
     ev_n = oracle.evaluate(o, oracle.JAC_NUMERIC, loss, loss_scale, apply_loss=True)
     out = {"name": name, "problem": dump_problem(prob), "loss": loss, "loss_scale": loss_scale,
-           "max_num_iterations": max_it,
+           "max_num_iterations": max_it, "extra_options": extra,
            "evaluate": {"cost": ev_a["cost"], "residuals": ev_a["residuals"].tolist(),
                         "jac_pose_analytic": ev_a["jac_pose"].tolist(), "jac_point_analytic": ev_a["jac_point"].tolist(),
                         "jac_pose_numeric": ev_n["jac_pose"].tolist(), "jac_point_numeric": ev_n["jac_point"].tolist()}}
     for mode, key in ((oracle.JAC_ANALYTIC, "solve_analytic"), (oracle.JAC_NUMERIC, "solve_numeric")):
         q = to_oracle(prob)
         s, its = oracle.solve(q, oracle.default_options(loss=loss, loss_scale=loss_scale, max_num_iterations=max_it,
-                                                        jacobian_mode=mode))
+                                                        jacobian_mode=mode, **extra))
         s.pop("time_evaluate_s"); s.pop("time_linear_solve_s"); s.pop("time_total_s")
         out[key] = {"summary": s, "iterations": its, "poses": q.poses.tolist(), "points": q.points.tolist()}
+    # the same solve with the parameter-tolerance test held back until one step has been accepted (not an
+    # upstream Ceres rule; hipba_options::parameter_tolerance_needs_success = 1)
+    q = to_oracle(prob)
+    s, its = oracle.solve(q, oracle.default_options(loss=loss, loss_scale=loss_scale, max_num_iterations=max_it,
+                                                    jacobian_mode=oracle.JAC_ANALYTIC, param_tol_needs_success=1, **extra))
+    s.pop("time_evaluate_s"); s.pop("time_linear_solve_s"); s.pop("time_total_s")
+    out["solve_analytic_needs_success"] = {"summary": s, "iterations": its, "poses": q.poses.tolist(),
+                                           "points": q.points.tolist()}
     return out
 
 
@@ -66,10 +74,19 @@ def main():
     _, _, poses, points, op, oq, uv = scenes._window(rng, 3, 20, 2, 3)
     pc, qc = scenes._production_constants(3, 20, op, oq)
     p_z = hipba.Problem(poses, points, op, oq, uv, scenes.KITTI_K, hipba.CAMERA_Z_FORWARD, pc, qc)
+    # the same window started from its own converged solution (what a sliding window mostly looks like when the
+    # optimizer is called again): tightened first, so that the very first step is below the parameter tolerance
+    conv = to_oracle(p_z)
+    oracle.solve(conv, oracle.default_options(max_num_iterations=300, jacobian_mode=oracle.JAC_ANALYTIC,
+                                              function_tolerance=1e-14, parameter_tolerance=1e-14))
+    p_conv = hipba.Problem(conv.poses, conv.points, op, oq, uv, scenes.KITTI_K, hipba.CAMERA_Z_FORWARD, pc, qc)
     cases = [
         case("ba_data_ba_test_semantics", p_test, oracle.LOSS_HUBER, 1.0, 50),
         case("ba_data_production_semantics", p_prod, oracle.LOSS_NONE, 1.0, 300),
         case("zforward_3pose_20point_production", p_z, oracle.LOSS_NONE, 1.0, 300),
+        case("zforward_3pose_20point_converged_start", p_conv, oracle.LOSS_NONE, 1.0, 300),
+        # ... and with the function tolerance out of the way, where the two parameter-tolerance rules part
+        case("zforward_3pose_20point_converged_start_ftol0", p_conv, oracle.LOSS_NONE, 1.0, 300, function_tolerance=0.0),
     ]
     # the same noisy instance in scene-file order, for the C++ harness (ba_test --noisy)
     with open(os.path.join(HERE, "ba_data_noisy.txt"), "w") as f:

@@ -34,7 +34,7 @@ def assert_logs_match(g_its, o_its, rtol=1e-6):
         assert abs(a["trust_region_radius"] - b["trust_region_radius"]) <= 1e-6 * b["trust_region_radius"]
 
 
-@pytest.mark.parametrize("case_index", [0, 1, 2])
+@pytest.mark.parametrize("case_index", [0, 1, 2, 3])
 def test_evaluate_matches_golden_and_oracle(solver, oracle, golden, case_index):
     case = golden["cases"][case_index]
     p = problem_from_dict(case["problem"], hipba.Problem)
@@ -54,12 +54,23 @@ def test_evaluate_matches_golden_and_oracle(solver, oracle, golden, case_index):
     assert rel(g2["residuals"], o2["residuals"]) <= RTOL_JAC and rel(g2["jac_pose"], o2["jac_pose"]) <= RTOL_JAC
 
 
-@pytest.mark.parametrize("case_index", [0, 1, 2])
+@pytest.mark.parametrize("case_index", [0, 1, 2, 3, 4])
 def test_solve_matches_golden(solver, golden, case_index):
     case = golden["cases"][case_index]
     p = problem_from_dict(case["problem"], hipba.Problem)
     opts = hipba.default_options(loss=case["loss"], loss_scale=case["loss_scale"],
-                                 max_num_iterations=case["max_num_iterations"])
+                                 max_num_iterations=case["max_num_iterations"], **case["extra_options"])
+    # the parameter-tolerance test held back until a step has been accepted (not upstream Ceres; an option on both sides)
+    p1 = problem_from_dict(case["problem"], hipba.Problem)
+    o1 = hipba.default_options(loss=case["loss"], loss_scale=case["loss_scale"], parameter_tolerance_needs_success=1,
+                               max_num_iterations=case["max_num_iterations"], **case["extra_options"])
+    s1 = solver.solve(p1, o1)
+    g1 = case["solve_analytic_needs_success"]
+    assert s1["termination_type"] == g1["summary"]["termination_type"]
+    assert s1["num_iterations"] == g1["summary"]["num_iterations"]
+    assert_logs_match(s1["iterations"], g1["iterations"])
+    assert np.abs(p1.poses - np.array(g1["poses"])).max() <= ATOL_STATE
+    # upstream rule (the default): tested on every valid step
     s = solver.solve(p, opts)
     for key in ("solve_analytic", "solve_numeric"):  # numeric = the reference's differentiation
         g = case[key]
@@ -230,9 +241,35 @@ def test_edge_cases(solver, oracle):
     g = d2.copy()
     s = solver.solve(g, hipba.reference_production_options())
     o = to_oracle(oracle, d2)
-    so, _ = oracle.solve(o, oracle.default_options(max_num_iterations=300, jacobian_mode=oracle.JAC_ANALYTIC))
+    so, oits = oracle.solve(o, oracle.default_options(max_num_iterations=300, jacobian_mode=oracle.JAC_ANALYTIC))
     assert abs(s["final_cost"] - so["final_cost"]) <= RTOL_COST * so["final_cost"]
     assert np.abs(g.poses - o.poses).max() <= ATOL_STATE
+    assert_logs_match(s["iterations"], oits)
+
+
+@pytest.mark.parametrize("scene", ["small_lds", "window_atomics", "gathered"])
+def test_repeated_observations_of_a_landmark_by_one_pose(solver, oracle, scene):
+    """Two residual blocks on the same (pose, landmark) pair are legal in ceres::Problem (optimizer.cpp:47-50 adds one
+    per feature).  Their cross term lands on the DIAGONAL block of the reduced matrix, which needs the product in both
+    orders: an error there still converges, so the per-iteration log is compared, in every accumulation mode."""
+    if scene == "small_lds":
+        prob, _, _ = scenes.small_window(4207, n_frames=8, n_points=300)
+    elif scene == "window_atomics":
+        prob, _, _ = scenes.small_window(4208, n_frames=36, n_points=500)   # 35 variable poses: fp64 atomics into HBM
+    else:
+        prob, _, _ = scenes.bal_scale(seed=31, grid=(10, 10), n_points=60000, depth_lo=5.0, depth_hi=30.0)  # gather
+    rng = np.random.default_rng(3)
+    n = prob.obs_pose.shape[0]
+    pick = rng.choice(n, size=n // 10, replace=False)
+    twice = np.concatenate([pick, pick[: len(pick) // 4]])  # some observed three times
+    d = hipba.Problem(prob.poses, prob.points, np.concatenate([prob.obs_pose, prob.obs_pose[twice]]),
+                      np.concatenate([prob.obs_point, prob.obs_point[twice]]),
+                      np.concatenate([prob.obs_uv, prob.obs_uv[twice] + rng.normal(0, 0.3, (len(twice), 2))]),
+                      prob.K, prob.camera_model, prob.pose_const, prob.point_const)
+    g = d.copy()
+    iters = 300 if scene != "gathered" else 6
+    s = solver.solve(g, hipba.default_options(max_num_iterations=iters))
+    _check_against_oracle(oracle, d, g, s, max_iter=iters)
 
 
 def test_resident_problem_reset_and_resolve_is_reproducible(solver):
@@ -277,18 +314,13 @@ def test_full_size_properties_bal_scale(solver):
     dp.free()
 
 
-def test_sharded_solve_equals_unsharded(oracle):
-    """Two ranks on one GPU (threads, each with its own handle and stream); the all-reduce callback
-    stages through host memory.  Exercises the reduce/decide kernel modes and the owner rule without RCCL."""
+def run_threaded_ranks(prob, opts, world=2, timeout=300):
+    """`world` ranks on one GPU (threads, each with its own handle and stream); the all-reduce callback stages
+    through host memory.  Returns [(summary, poses, points, lo, hi)] per rank."""
     import ctypes as C
     hip = C.CDLL("libamdhip64.so")  # the callback stages through host memory with plain HIP copies
     hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     hip.hipStreamSynchronize.argtypes = [C.c_void_p]
-    prob, _, _ = scenes.bal_scale(seed=5, grid=(6, 7), n_points=6000, depth_lo=5.0, depth_hi=25.0)
-    opts = lambda: hipba.default_options(max_num_iterations=6)
-    ref = prob.copy()
-    s_ref = hipba.Solver(0).solve(ref, opts())
-    world = 2
     barrier = threading.Barrier(world)
     slots = [None] * world
     results = [None] * world
@@ -300,9 +332,9 @@ def test_sharded_solve_equals_unsharded(oracle):
                 mine = np.empty(count, dtype=np.float64)
                 assert hip.hipMemcpy(mine.ctypes.data, buf, 8 * count, 2) == 0   # device to host
                 slots[rank] = mine
-                barrier.wait(timeout=60)
+                barrier.wait(timeout=timeout)
                 tot = np.sum(slots, axis=0) if op == hipba.REDUCE_SUM else np.max(slots, axis=0)
-                barrier.wait(timeout=60)
+                barrier.wait(timeout=timeout)
                 assert hip.hipMemcpy(buf, tot.ctypes.data, 8 * count, 1) == 0    # host to device
                 return 0
             except Exception as e:  # pragma: no cover
@@ -323,13 +355,54 @@ def test_sharded_solve_equals_unsharded(oracle):
 
     th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
     for t in th: t.start()
-    for t in th: t.join(timeout=120)
+    for t in th: t.join(timeout=timeout)
     assert all(r is not None for r in results)
+    return results
+
+
+def test_sharded_solve_equals_unsharded(oracle):
+    """Two ranks on one GPU.  Exercises the reduce/decide kernel modes and the owner rule without RCCL."""
+    prob, _, _ = scenes.bal_scale(seed=5, grid=(6, 7), n_points=6000, depth_lo=5.0, depth_hi=25.0)
+    opts = lambda: hipba.default_options(max_num_iterations=6)
+    ref = prob.copy()
+    s_ref = hipba.Solver(0).solve(ref, opts())
+    results = run_threaded_ranks(prob, opts)
     for s, poses, pts, lo, hi in results:
         assert s["termination_type"] == s_ref["termination_type"] and s["num_iterations"] == s_ref["num_iterations"]
         assert abs(s["final_cost"] - s_ref["final_cost"]) <= 1e-9 * s_ref["final_cost"]
         assert np.abs(poses - ref.poses).max() <= 1e-8
         assert np.abs(pts - ref.points[lo:hi]).max() <= 1e-7
+
+
+def test_sharded_solve_with_gathered_elimination_equals_unsharded():
+    """The multi-GPU configuration of the BAL-scale problem in small: every shard is large enough (more than 20
+    cameras, at least 2M observation pairs) for the per-block gather, whose blocks then go to the packed reduced
+    matrix (zeroed every iteration, diagonal blocks added atomically onto the owner's U + D^2, summed over ranks
+    and unpacked for the factorisation) instead of straight into the dense matrix."""
+    prob, _, _ = scenes.bal_scale(seed=37, grid=(10, 10), n_points=120000, depth_lo=5.0, depth_hi=30.0)
+    opts = lambda: hipba.default_options(max_num_iterations=5)
+    ref = prob.copy()
+    sv = hipba.Solver(0)
+    s_ref = sv.solve(ref, opts())
+    sv.close()
+    results = run_threaded_ranks(prob, opts)
+    for s, poses, pts, lo, hi in results:
+        assert s["termination_type"] == s_ref["termination_type"] and s["num_iterations"] == s_ref["num_iterations"]
+        assert abs(s["final_cost"] - s_ref["final_cost"]) <= 1e-9 * s_ref["final_cost"]
+        assert np.abs(poses - ref.poses).max() <= 1e-8
+        assert np.abs(pts - ref.points[lo:hi]).max() <= 1e-7
+
+
+def test_time_breakdown_is_reported_on_request(solver):
+    # FullReport's split (optimizer.cpp:62 prints it): device time per phase, summed over the iterations
+    prob, _, _ = scenes.kitti_like_window(1002)
+    a = solver.solve(prob.copy(), hipba.reference_production_options(), log=False)
+    assert a["time_linear_solver_s"] == 0.0 and a["time_residual_evaluation_s"] == 0.0
+    b = solver.solve(prob.copy(), hipba.reference_production_options(report_time_breakdown=1), log=False)
+    parts = (b["time_residual_evaluation_s"], b["time_jacobian_evaluation_s"], b["time_linear_solver_s"])
+    assert all(t > 0.0 for t in parts) and sum(parts) <= b["time_solve_s"]
+    assert b["time_linear_solver_s"] > b["time_residual_evaluation_s"]
+    assert b["num_iterations"] == a["num_iterations"] and b["final_cost"] == pytest.approx(a["final_cost"], rel=1e-12)
 
 
 def test_cpp_optimizer_adapter_through_ba_test_cli(golden):

@@ -123,11 +123,13 @@ def test_oracle_reproduces_golden(oracle, golden):
         ev = oracle.evaluate(to_oracle(oracle, p), oracle.JAC_ANALYTIC, case["loss"], case["loss_scale"])
         np.testing.assert_allclose(ev["residuals"], np.array(case["evaluate"]["residuals"]), rtol=1e-13, atol=1e-13)
         np.testing.assert_allclose(ev["jac_pose"], np.array(case["evaluate"]["jac_pose_analytic"]), rtol=1e-13, atol=1e-12)
-        for mode, key in ((oracle.JAC_ANALYTIC, "solve_analytic"), (oracle.JAC_NUMERIC, "solve_numeric")):
+        extra = case.get("extra_options", {})
+        for mode, key, flag in ((oracle.JAC_ANALYTIC, "solve_analytic", 0), (oracle.JAC_NUMERIC, "solve_numeric", 0),
+                                (oracle.JAC_ANALYTIC, "solve_analytic_needs_success", 1)):
             q = to_oracle(oracle, p)
             s, its = oracle.solve(q, oracle.default_options(loss=case["loss"], loss_scale=case["loss_scale"],
                                                             max_num_iterations=case["max_num_iterations"],
-                                                            jacobian_mode=mode))
+                                                            jacobian_mode=mode, param_tol_needs_success=flag, **extra))
             g = case[key]
             assert s["termination_type"] == g["summary"]["termination_type"]
             assert s["num_iterations"] == g["summary"]["num_iterations"]
@@ -158,7 +160,7 @@ def test_ba_test_semantics_recovers_zero_cost(golden):
 def test_full_normal_equations_equal_schur(oracle, golden):
     # SPARSE_NORMAL_CHOLESKY on the whole system (what the reference asks Ceres for) and the
     # landmark-eliminated system give the same step when both are solved exactly
-    for ci, case in enumerate(golden["cases"]):
+    for ci, case in enumerate(golden["cases"][:3]):  # (the converged-start cases have a zero step: nothing to compare)
         p = problem_from_dict(case["problem"], hipba.Problem)
         o = to_oracle(oracle, p)
         # case 0 has no gauge fixing (ba_test.cpp:243-267): with almost no damping the step is only
@@ -208,3 +210,17 @@ def test_failure_leaves_inputs_untouched(oracle):
     assert s["termination_type"] == oracle.FAILURE
     np.testing.assert_array_equal(p.poses, poses)
     np.testing.assert_array_equal(p.points, points)
+
+
+def test_parameter_tolerance_rule_only_matters_from_a_converged_start(golden):
+    """Upstream Ceres tests the parameter tolerance on every valid step; holding the test back until a step has been
+    accepted (an option of the oracle and of the engine) changes no iteration log of the reference-shaped cases and
+    only shows when a window starts at its optimum with the function tolerance switched off."""
+    for case in golden["cases"]:
+        a, b = case["solve_analytic"], case["solve_analytic_needs_success"]
+        same = [(x["iteration"], x["step_is_successful"], x["cost"]) for x in a["iterations"]] == \
+               [(x["iteration"], x["step_is_successful"], x["cost"]) for x in b["iterations"]]
+        assert same == (case["name"] != "zforward_3pose_20point_converged_start_ftol0"), case["name"]
+    c = golden["cases"][-1]
+    assert c["solve_analytic"]["summary"]["num_iterations"] == 1            # first step already below the tolerance
+    assert c["solve_analytic_needs_success"]["summary"]["num_iterations"] > 1
