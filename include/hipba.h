@@ -224,6 +224,26 @@ int hipba_evaluate(hipba_handle h, const hipba_problem* problem, const hipba_opt
                    int apply_loss, double* cost, double* residuals, double* jac_pose,
                    double* jac_point);
 
+/*
+ * hipba_evaluate for callers that CANNOT ALLOCATE device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  No counterpart in the reference: it exists for those callers only.
+ * Every array argument is a DEVICE pointer the caller owns (same shapes and meaning as hipba_evaluate; any
+ * output may be NULL; d_cost receives one double); constant flags do not exist here.  The call allocates and
+ * frees nothing, on the host link or the device: the one buffer its kernels need beyond inputs and outputs (a
+ * partial cost sum per 256 observations) is a fixed array inside the library, 512 KB on every GPU the library
+ * runs on, which limits one call to HIPBA_EVALUATE_DEVICE_MAX_OBS observations (more: HIPBA_ERR_UNSUPPORTED).
+ * The work is QUEUED on the handle's stream (hipba_stream) and the call returns without waiting; outputs are
+ * valid once that stream has reached this point.  All calls on one GPU share the array: calls that overlap on
+ * one GPU (two handles, two streams) race on the cost sum -- serialise them.  Indices cannot be checked on the
+ * host: an observation whose pose or landmark index is out of range yields NaN outputs and a NaN cost.
+ */
+#define HIPBA_EVALUATE_DEVICE_MAX_OBS (1 << 24)
+int hipba_evaluate_device(hipba_handle h, int32_t n_poses, const double* d_poses, int32_t n_points,
+                          const double* d_points, int64_t n_obs, const int32_t* d_obs_pose,
+                          const int32_t* d_obs_point, const double* d_obs_uv, double fx, double fy, double cx,
+                          double cy, int32_t camera_model, const hipba_options* options, int apply_loss,
+                          double* d_cost, double* d_residuals, double* d_jac_pose, double* d_jac_point);
+
 /* ---- device-resident problems: upload once, solve/reset many times ---------------------- */
 int hipba_upload(hipba_handle h, int32_t n_windows, const hipba_problem* problems,
                  hipba_device_problem* out);

@@ -124,8 +124,38 @@ class HostWorkers {
   std::atomic<bool> failed_{false};
 };
 
+// ---- scratch of hipba_evaluate_device ---------------------------------------------------------------
+// That entry point serves callers that cannot allocate, so the one buffer its kernels need beyond the caller's
+// inputs and outputs -- the per-workgroup partial sums of the cost, one double per 256 observations -- lives in the
+// code object itself.  Every GPU the library runs on holds its own copy (512 KB) until the process ends.  In host
+// code the NAME of the array is not a device address: the address on a device comes from hipGetSymbolAddress, asked
+// once per device with that device current (scratch_on_device, called by hipba_create), and only that pointer is
+// ever handed to a kernel.  Nothing in it has to start at zero: a call overwrites every word it reads.
+static __device__ __align__(256) double scratch[HIPBA_EVALUATE_DEVICE_MAX_OBS / kBlock];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+double* g_scratch_ptr[kMaxDevices] = {};
+
+// device address of `scratch` on `device`, which must be the current device
+hipError_t scratch_on_device(int device, double** out) {
+  if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+  std::lock_guard<std::mutex> lk(g_scratch_mutex);
+  if (!g_scratch_ptr[device]) {
+    double* ptr = nullptr;
+    const hipError_t e = hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    g_scratch_ptr[device] = ptr;
+  }
+  *out = g_scratch_ptr[device];
+  return hipSuccess;
+}
+}  // namespace
+
 struct hipba_handle_s {
   int device = 0;
+  double* eval_scratch = nullptr;  // this device's copy of `scratch` (see above)
   HostWorkers workers;
   hipStream_t stream = nullptr;
   // grow-only buffers reused by hipba_solve / hipba_solve_batched
@@ -1242,8 +1272,11 @@ int hipba_create(int device, hipba_handle* out) {
     // kernel attributes are per device: set them for this handle's device whatever other handles have done
     HIPBA_HIP(configure_lm_kernels());
     HIPBA_HIP(configure_dense_kernels());
+    double* eval_scratch = nullptr;
+    HIPBA_HIP(scratch_on_device(device, &eval_scratch));
     auto* h = new hipba_handle_s();
     h->device = device;
+    h->eval_scratch = eval_scratch;
     e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_count, 64, hipHostMallocDefault);
     for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&h->poll_ev[i], hipEventDisableTiming);
@@ -1459,6 +1492,39 @@ int hipba_evaluate(hipba_handle h, const hipba_problem* p, const hipba_options* 
     rc = body();
     (void)hipFree(base);
     return rc;
+  });
+}
+
+int hipba_evaluate_device(hipba_handle h, int32_t n_poses, const double* d_poses, int32_t n_points, const double* d_points,
+                          int64_t n_obs, const int32_t* d_obs_pose, const int32_t* d_obs_point, const double* d_obs_uv,
+                          double fx, double fy, double cx, double cy, int32_t camera_model, const hipba_options* options,
+                          int apply_loss, double* d_cost, double* d_residuals, double* d_jac_pose, double* d_jac_point) {
+  return guarded([&]() -> int {
+    if (!h) return fail(HIPBA_ERR_INVALID_ARGUMENT, "null handle");
+    if (n_poses < 0 || n_points < 0 || n_obs < 0) return fail(HIPBA_ERR_INVALID_ARGUMENT, "negative size");
+    if (n_obs > (int64_t)HIPBA_EVALUATE_DEVICE_MAX_OBS)
+      return fail(HIPBA_ERR_UNSUPPORTED, "hipba_evaluate_device takes at most %lld observations per call (got %lld): "
+                  "its scratch is a fixed array in the library; split the call or use hipba_evaluate",
+                  (long long)HIPBA_EVALUATE_DEVICE_MAX_OBS, (long long)n_obs);
+    if (camera_model != HIPBA_CAMERA_Z_FORWARD && camera_model != HIPBA_CAMERA_X_FORWARD)
+      return fail(HIPBA_ERR_INVALID_ARGUMENT, "unknown camera model %d", camera_model);
+    if (n_obs && (!d_poses || !d_points || !d_obs_pose || !d_obs_point || !d_obs_uv))
+      return fail(HIPBA_ERR_INVALID_ARGUMENT, "null input array");
+    if (!h->eval_scratch) return fail(HIPBA_ERR_HIP, "the handle has no scratch address");
+    hipba_options o;
+    if (options) o = *options; else hipba_options_default(&o);
+    HIPBA_HIP(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    if (n_obs == 0) {
+      if (d_cost) HIPBA_HIP(hipMemsetAsync(d_cost, 0, sizeof(double), s));
+      return HIPBA_OK;
+    }
+    const CameraK K{fx, fy, cx, cy, camera_model};
+    // the partial sums go to this device's copy of the library's scratch array: nothing is allocated here
+    HIPBA_HIP(launch_residual_jacobian(K, make_lm(o), apply_loss, n_obs, n_poses, n_points, d_poses, d_points, d_obs_pose,
+                                       d_obs_point, d_obs_uv, d_residuals, d_jac_pose, d_jac_point,
+                                       d_cost ? h->eval_scratch : nullptr, d_cost, s));
+    return HIPBA_OK;
   });
 }
 

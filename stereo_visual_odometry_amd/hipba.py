@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libhipba.so")
 OK = 0
 ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_OUT_OF_MEMORY, ERR_UNSUPPORTED, ERR_COMM, ERR_INTERNAL = (
     -1, -2, -3, -4, -5, -6, -7)
+EVALUATE_DEVICE_MAX_OBS = 1 << 24  # HIPBA_EVALUATE_DEVICE_MAX_OBS
 CAMERA_Z_FORWARD, CAMERA_X_FORWARD = 0, 1
 ABI_VERSION = 102  # HIPBA_VERSION of the include/hipba.h these ctypes structures mirror
 LOSS_NONE, LOSS_HUBER = 0, 1
@@ -93,7 +94,7 @@ class CComm(C.Structure):
 # every symbol include/hipba.h declares
 EXPORTED_SYMBOLS = [
     "hipba_version", "hipba_last_error", "hipba_options_default", "hipba_create", "hipba_destroy", "hipba_stream",
-    "hipba_solve", "hipba_solve_batched", "hipba_evaluate", "hipba_upload", "hipba_upload_shard", "hipba_reset", "hipba_solve_device",
+    "hipba_solve", "hipba_solve_batched", "hipba_evaluate", "hipba_evaluate_device", "hipba_upload", "hipba_upload_shard", "hipba_reset", "hipba_solve_device",
     "hipba_solve_device_sharded", "hipba_download", "hipba_free_problem", "hipba_time_kernel",
 ]
 
@@ -131,6 +132,10 @@ def load_library(path=None):
     lib.hipba_solve_batched.argtypes = [C.c_void_p, C.c_int32, C.POINTER(CProblem), C.POINTER(COptions),
                                         C.POINTER(CSummary)]
     lib.hipba_evaluate.argtypes = [C.c_void_p, C.POINTER(CProblem), C.POINTER(COptions), C.c_int, _dp, _dp, _dp, _dp]
+    lib.hipba_evaluate_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double,
+                                          C.c_double, C.c_int32, C.POINTER(COptions), C.c_int, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p]
     lib.hipba_upload.argtypes = [C.c_void_p, C.c_int32, C.POINTER(CProblem), C.POINTER(C.c_void_p)]
     lib.hipba_upload_shard.argtypes = [C.c_void_p, C.POINTER(CProblem), C.POINTER(C.c_void_p)]
     lib.hipba_reset.argtypes = [C.c_void_p, C.c_void_p]
@@ -336,6 +341,17 @@ class Solver:
                                         C.cast(C.byref(cost), _dp), res.ctypes.data_as(_dp),
                                         jc.ctypes.data_as(_dp), jp.ctypes.data_as(_dp)))
         return {"cost": cost.value, "residuals": res, "jac_pose": jc, "jac_point": jp}
+
+    def evaluate_device(self, n_poses, d_poses, n_points, d_points, n_obs, d_obs_pose, d_obs_point, d_obs_uv, K,
+                        camera_model=CAMERA_Z_FORWARD, options=None, apply_loss=True, d_cost=None, d_residuals=None,
+                        d_jac_pose=None, d_jac_point=None):
+        """hipba_evaluate_device: every d_* is a device address (int) owned by the caller; the work is queued on
+        this handle's stream and nothing is allocated.  Synchronise the stream before reading the outputs."""
+        o = options if options is not None else default_options()
+        _check(self._lib.hipba_evaluate_device(self._h, n_poses, d_poses, n_points, d_points, n_obs, d_obs_pose,
+                                               d_obs_point, d_obs_uv, K[0], K[1], K[2], K[3], camera_model,
+                                               C.byref(o), int(bool(apply_loss)), d_cost, d_residuals, d_jac_pose,
+                                               d_jac_point))
 
     def upload(self, problems):
         if isinstance(problems, Problem):
