@@ -6,15 +6,21 @@
 A step is ONE Levenberg-Marquardt iteration (linearise, eliminate landmarks, solve the reduced
 camera system, back-substitute, evaluate the candidate, accept/reject) on the BAL-scale synthetic
 problem of BASELINE.json (2000 cameras x 1M landmarks x 8M observations), resident in HBM before
-the timed region starts.  With N > 1 (launched by torch.distributed.run, one rank per GPU) the same
-problem is sharded by landmark and the reduced camera matrix / right-hand side are all-reduced over
-RCCL every iteration: strong scaling, value = iterations of the whole job per second.
+the timed region starts, solved with Ceres' default tolerances from a poor starting point so that the
+K timed iterations are a real descent (accepted and rejected steps are reported).  With N > 1
+(launched by torch.distributed.run, one rank per GPU) the same problem is sharded by landmark and
+the reduced camera matrix / right-hand side are all-reduced over RCCL every iteration: strong
+scaling, value = iterations of the whole job per second.
 
 Rank 0 prints ONE JSON line carrying the metric, the roofline of the dominant kernel (durations
 measured here with HIP events on the engine's stream), and a CPU baseline (the restated-Ceres
-oracle on the host cores, on a bounded sample).
+oracle on the host cores, on a bounded sample); under "secondary" the other single-GPU
+configurations of BASELINE.json (ms per KITTI-like keyframe window, batched small windows), each
+with its own roofline and its own CPU baseline on the same inputs.
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -27,6 +33,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E, spec
 FP64_PEAK_TFLOPS = 78.6    # MI355X fp64 matrix / vector, spec
+TERMINATION = ["CONVERGENCE", "NO_CONVERGENCE", "FAILURE"]
 
 
 def algorithmic_bytes(kernel, n_c, n_p, n_o, nnz_s):
@@ -44,9 +51,8 @@ def algorithmic_bytes(kernel, n_c, n_p, n_o, nnz_s):
     raise KeyError(kernel)
 
 
-def count_reduced_nonzeros(prob, degree_hint=None):
+def count_reduced_nonzeros(prob):
     """36 x number of co-visible camera pairs (diagonal included, both triangles) of the reduced matrix."""
-    from stereo_visual_odometry_amd import hipba  # noqa: F401
     n_c = prob.poses.shape[0]
     order = np.argsort(prob.obs_point, kind="stable")
     pt, cam = prob.obs_point[order], prob.obs_pose[order].astype(np.int64)
@@ -63,17 +69,69 @@ def count_reduced_nonzeros(prob, degree_hint=None):
     return 36 * int(seen.sum())
 
 
+def csrc_fingerprint():
+    """sha256 over the kernel sources: profiles/traffic.json carries the fingerprint of the sources its counters
+    were collected on, and is ignored when the kernels have changed since."""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "stereo_visual_odometry_amd", "csrc", "*.h*"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+def load_traffic(workload_key):
+    """HBM bytes per launch from rocprofv3 PMC passes (scripts/profile_target.py + scripts/summarize_pmc.py), or {}
+    if the file is absent, was measured on another workload or on other kernel sources."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(path):
+        return {}
+    tr = json.load(open(path))
+    if tr.get("csrc_sha256") != csrc_fingerprint() or tr.get("workload") != workload_key:
+        return {}
+    return tr.get("kernels", {})
+
+
+def kernel_table(dp, hipba, opts, n_c, n_p, n_o, nnz, flops_solve, single_window):
+    """Average launch duration of every hot-path kernel on the resident problem (HIP events on the engine's
+    stream) against its algorithmic bytes / flops."""
+    rows = []
+    for kid, name in enumerate(hipba.KERNEL_NAMES):
+        if name == "residual_jacobian" and not single_window:
+            continue  # the materialising twin is not part of the loop and is timed on one-window problems only
+        ms = dp.time_kernel(kid, 5 if name != "reduced_solve" else 2, opts)
+        if name == "reduced_solve":
+            ach = flops_solve / (ms * 1e-3) / 1e12
+            rows.append({"kernel": name, "bound": "mfma", "ms": ms, "achieved": ach, "peak": FP64_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS, "traffic": None})
+        else:
+            ach = algorithmic_bytes(name, n_c, n_p, n_o, nnz) / (ms * 1e-3) / 1e9
+            rows.append({"kernel": name, "bound": "hbm", "ms": ms, "achieved": ach, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None})
+    return rows
+
+
+def roofline_of(rows):
+    in_loop = [k for k in rows if k["kernel"] != "residual_jacobian"]
+    dom = max(in_loop, key=lambda k: k["ms"])
+    out = {k: dom[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
+    out["kernel"] = dom["kernel"]
+    return out
+
+
+def oracle_problem(oracle, p):
+    return oracle.Problem(p.poses, p.points, p.obs_pose, p.obs_point, p.obs_uv, p.K, p.camera_model, p.pose_const,
+                          p.point_const)
+
+
 def cpu_baseline(threads):
     """The CPU oracle (restated Ceres path: numeric central-difference Jacobians, exact solve) on a
-    1/8-scale sample of the workload."""
+    1/8-scale sample of the workload, same scene generator and starting noise."""
     from oracle import oracle
     from stereo_visual_odometry_amd import scenes
-    prob, _, _ = scenes.bal_scale(seed=3000, grid=(10, 25), n_points=125_000)
-    o = oracle.Problem(prob.poses, prob.points, prob.obs_pose, prob.obs_point, prob.obs_uv, prob.K,
-                       prob.camera_model, prob.pose_const, prob.point_const)
+    prob, _, _ = scenes.bal_scale_hard(seed=3000, grid=(10, 25), n_points=125_000)
+    o = oracle_problem(oracle, prob)
     iters = 3
-    opts = oracle.default_options(max_num_iterations=iters, num_threads=threads, function_tolerance=0.0,
-                                  gradient_tolerance=0.0, parameter_tolerance=0.0)
+    opts = oracle.default_options(max_num_iterations=iters, num_threads=threads)
     t0 = time.time()
     s, its = oracle.solve(o, opts)
     dt = time.time() - t0
@@ -81,44 +139,91 @@ def cpu_baseline(threads):
     return {
         "value": done / dt, "unit": "LM iterations/s", "cores": threads, "kind": "port",
         "sample": "restated-Ceres oracle (numeric central-difference Jacobians, exact Schur+Cholesky solve), "
-                  "%d LM iterations on a 1/8-scale problem: 250 cameras x 125k landmarks x 1M observations "
-                  "(evaluate %.2fs, linear solve %.2fs); the full-size problem has 8x the observations and a "
-                  "512x larger factorisation" % (done, s["time_evaluate_s"], s["time_linear_solve_s"]),
+                  "%d LM iterations on a 1/8-scale problem from the same generator: 250 cameras x 125k landmarks x "
+                  "1M observations (evaluate %.2fs, linear solve %.2fs); the full-size problem has 8x the observations "
+                  "and a 512x larger factorisation" % (done, s["time_evaluate_s"], s["time_linear_solve_s"]),
     }
 
 
-def secondary_measurements(solver):
+def secondary_measurements(solver, with_cpu, threads):
     """ms per KITTI-like keyframe window (end to end through hipba_solve, upload included) and batched
-    small-window throughput -- the other two single-GPU configurations of BASELINE.json."""
+    small-window throughput -- the other two single-GPU configurations of BASELINE.json -- each with the roofline
+    of its dominant kernel and the CPU oracle timed on the same inputs."""
     from stereo_visual_odometry_amd import hipba, scenes
     out = {}
+    opts = hipba.reference_production_options()
     wins = [scenes.kitti_like_window(1000 + i)[0] for i in range(8)]
-    solver.solve(wins[0].copy(), hipba.reference_production_options(), log=False)  # warm-up
+    solver.solve(wins[0].copy(), opts, log=False)  # warm-up
     t, iters = [], []
     for w in wins:
         p = w.copy()
         t0 = time.perf_counter()
-        s = solver.solve(p, hipba.reference_production_options(), log=False)
+        s = solver.solve(p, opts, log=False)
         t.append(time.perf_counter() - t0)
         iters.append(s["num_iterations"] - 1)
-    out["kitti_like_window"] = {
-        "ms_per_window": 1e3 * float(np.mean(t)), "lm_iterations_per_window": float(np.mean(iters)),
-        "workload": "30 keyframes, ~4000 landmarks, ~25k observations, production semantics "
-                    "(first frame constant, 300 iteration budget), host upload included"}
+    kw = {"ms_per_window": 1e3 * float(np.mean(t)), "lm_iterations_per_window": float(np.mean(iters)),
+          "lm_iterations_per_s": float(np.sum(iters) / np.sum(t)),
+          "workload": "30 keyframes, ~4000 landmarks, ~25k observations, production semantics "
+                      "(first frame constant, 300 iteration budget), host upload included; mean of 8 windows"}
+    # per-kernel durations on window 0, resident
+    w0 = wins[0]
+    dp = solver.upload(w0)
+    n_c, n_p, n_o = w0.poses.shape[0], w0.points.shape[0], w0.obs_pose.shape[0]
+    rows = kernel_table(dp, hipba, opts, n_c, n_p, n_o, 36 * n_c * n_c, (6.0 * (n_c - 1)) ** 3 / 3.0, True)
+    dp.free()
+    kw["roofline"] = roofline_of(rows)
+    kw["kernels"] = rows
+    if with_cpu:
+        from oracle import oracle
+        tc, itc = [], []
+        for w in wins:
+            o = oracle_problem(oracle, w)
+            t0 = time.perf_counter()
+            so, its = oracle.solve(o, oracle.default_options(max_num_iterations=300, num_threads=threads))
+            tc.append(time.perf_counter() - t0)
+            itc.append(len(its) - 1)
+        kw["cpu_baseline"] = {"value": 1e3 * float(np.mean(tc)), "unit": "ms per window", "cores": threads, "kind": "port",
+                              "lm_iterations_per_window": float(np.mean(itc)),
+                              "sample": "restated-Ceres oracle (numeric central-difference Jacobians, full normal "
+                                        "equations solved exactly) on the same 8 windows"}
+    out["kitti_like_window"] = kw
+
     n_w = 1024
     small = [scenes.small_window(2000 + i)[0] for i in range(n_w)]
     dp = solver.upload(small)
-    opts = hipba.reference_production_options()
     dp.solve(opts)
     dp.reset()
     t0 = time.perf_counter()
     res = dp.solve(opts)
     dt = time.perf_counter() - t0
     tot_it = sum(r["num_iterations"] - 1 for r in res)
-    out["batched_small_windows"] = {
-        "windows": n_w, "windows_per_s": n_w / dt, "lm_iterations_per_s": tot_it / dt, "ms_total": 1e3 * dt,
-        "workload": "1024 windows x (10 keyframes, 2000 landmarks, ~14k observations), resident in HBM"}
+    bw = {"windows": n_w, "windows_per_s": n_w / dt, "lm_iterations_per_s": tot_it / dt, "ms_total": 1e3 * dt,
+          "workload": "1024 windows x (10 keyframes, 2000 landmarks, ~14k observations), resident in HBM"}
+    dp.reset()
+    n_c = sum(p.poses.shape[0] for p in small)
+    n_p = sum(p.points.shape[0] for p in small)
+    n_o = sum(p.obs_pose.shape[0] for p in small)
+    nnz = sum(36 * p.poses.shape[0] ** 2 for p in small)
+    flops = sum((6.0 * (p.poses.shape[0] - 1)) ** 3 / 3.0 for p in small)
+    rows = kernel_table(dp, hipba, opts, n_c, n_p, n_o, nnz, flops, False)
     dp.free()
+    bw["roofline"] = roofline_of(rows)
+    bw["kernels"] = rows
+    if with_cpu:
+        from oracle import oracle
+        n_cpu = 16
+        t0 = time.perf_counter()
+        itc = 0
+        for w in small[:n_cpu]:
+            o = oracle_problem(oracle, w)
+            so, its = oracle.solve(o, oracle.default_options(max_num_iterations=300, num_threads=threads))
+            itc += len(its) - 1
+        dtc = time.perf_counter() - t0
+        bw["cpu_baseline"] = {"value": n_cpu / dtc, "unit": "windows/s", "cores": threads, "kind": "port",
+                              "lm_iterations_per_s": itc / dtc,
+                              "sample": "restated-Ceres oracle (numeric central-difference Jacobians, exact solve) on the "
+                                        "first %d of the same 1024 windows, one after another" % n_cpu}
+    out["batched_small_windows"] = bw
     out["concurrent_sequences"] = concurrent_sequences(solver.device)
     return out
 
@@ -184,7 +289,7 @@ def replica_windows(solver, rank, world, fence, n_w=1024):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--points", type=int, default=1_000_000, help="landmarks of the BAL-scale problem")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -218,13 +323,14 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     solver = hipba.Solver(local_rank)
-    prob, _, _ = scenes.bal_scale(seed=3000, n_points=args.points)
+    prob, _, _ = scenes.bal_scale_hard(seed=3000, n_points=args.points)
     n_c, n_p, n_o = prob.poses.shape[0], prob.points.shape[0], prob.obs_pose.shape[0]
     lin = hipba.LINEAR_DENSE_CHOLESKY if args.linear_solver == "cholesky" else hipba.LINEAR_PCG
 
     def lm_options(iters):
-        return hipba.default_options(max_num_iterations=iters, function_tolerance=0.0, gradient_tolerance=0.0,
-                                     parameter_tolerance=0.0, linear_solver=lin, pcg_max_iterations=2000,
+        # Ceres' defaults everywhere (function 1e-6, gradient 1e-10, parameter 1e-8): the iteration budget alone
+        # is what the reference sets (optimizer.cpp:58)
+        return hipba.default_options(max_num_iterations=iters, linear_solver=lin, pcg_max_iterations=2000,
                                      pcg_tolerance=1e-10)
 
     if world > 1:
@@ -264,46 +370,37 @@ def main():
     if rank == 0:
         nnz = count_reduced_nonzeros(prob)
         # per-kernel durations with HIP events on the engine's stream (single-GPU shard of rank 0)
-        kernels = []
-        flops_chol = (6.0 * (n_c - 1)) ** 3 / 3.0
         shard_o = dp.problems[0].obs_pose.shape[0]
         shard_p = dp.problems[0].points.shape[0]
-        for kid, name in enumerate(hipba.KERNEL_NAMES):
-            ms = dp.time_kernel(kid, 5 if name != "reduced_solve" else 2, lm_options(1))
-            if name == "reduced_solve":
-                if lin == hipba.LINEAR_DENSE_CHOLESKY:
-                    ach = flops_chol / (ms * 1e-3) / 1e12
-                    kernels.append({"kernel": name, "bound": "mfma", "ms": ms, "achieved": ach, "peak": FP64_PEAK_TFLOPS,
-                                    "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS, "traffic": None})
-                else:
-                    kernels.append({"kernel": name, "bound": "hbm", "ms": ms, "achieved": None, "peak": HBM_PEAK_GBS,
-                                    "unit": "GB/s", "frac": None, "traffic": None})
-            else:
-                b = algorithmic_bytes(name, n_c, shard_p, shard_o, nnz)
-                ach = b / (ms * 1e-3) / 1e9
-                kernels.append({"kernel": name, "bound": "hbm", "ms": ms, "achieved": ach, "peak": HBM_PEAK_GBS,
-                                "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None})
-        traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(traffic_file):
-            tr = json.load(open(traffic_file))
+        flops_chol = (6.0 * (n_c - 1)) ** 3 / 3.0
+        if lin == hipba.LINEAR_DENSE_CHOLESKY:
+            kernels = kernel_table(dp, hipba, lm_options(1), n_c, shard_p, shard_o, nnz, flops_chol, True)
+        else:
+            kernels = [k for k in kernel_table(dp, hipba, lm_options(1), n_c, shard_p, shard_o, nnz, flops_chol, True)]
             for k in kernels:
-                # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE doubled, WRITE_SIZE; KiB units),
-                # collected on this workload by scripts/profile_target.py + scripts/summarize_pmc.py
-                if k["kernel"] in tr and (n_p, world) == (1_000_000, 1):
-                    k["traffic"] = tr[k["kernel"]]["hbm_bytes"]
-        in_loop = [k for k in kernels if k["kernel"] != "residual_jacobian"]
-        dom = max(in_loop, key=lambda k: k["ms"])
+                if k["kernel"] == "reduced_solve":
+                    k.update({"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None})
+        traffic = load_traffic("bal_scale %d %d %d world %d" % (n_c, n_p, n_o, world))
+        for k in kernels:
+            if k["kernel"] in traffic:
+                k["traffic"] = traffic[k["kernel"]]["hbm_bytes"]
+        roof = roofline_of(kernels)
         result = {
             "metric": "BA LM iterations/sec", "value": steps_done / elapsed, "unit": "LM iterations/s",
             "n_gpus": world, "steps": steps_done, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(steps_done, 1),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BAL-scale synthetic BA: %d cameras x %d landmarks x %d observations, "
-                                   "landmark-aligned observation shards over %d GPU(s), reduced camera system by %s"
-                                   % (n_c, n_p, n_o, world, "fp64 matrix-core Cholesky" if lin == 1 else "block-Jacobi PCG"),
+                                   "landmark-aligned observation shards over %d GPU(s), reduced camera system by %s; "
+                                   "start %.1f m / %.2f rad / %.1f m from the truth, Ceres default tolerances"
+                                   % (n_c, n_p, n_o, world, "fp64 matrix-core Cholesky" if lin == 1 else "block-Jacobi PCG",
+                                      scenes.HARD_START["sigma_t"], scenes.HARD_START["sigma_w"], scenes.HARD_START["sigma_p"]),
                        "cameras": n_c, "landmarks": n_p, "observations": n_o, "linear_solver": args.linear_solver,
+                       "termination_type": TERMINATION[summary["termination_type"]],
+                       "num_successful_steps": summary["num_successful_steps"] - 1,  # Ceres counts iteration 0 too
+                       "num_unsuccessful_steps": summary["num_unsuccessful_steps"],
                        "final_cost": summary["final_cost"], "initial_cost": summary["initial_cost"]},
-            "roofline": {k: dom[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")},
-            "roofline_kernel": dom["kernel"],
+            "roofline": {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")},
+            "roofline_kernel": roof["kernel"],
             "kernels": kernels,
         }
         if world > 1:
@@ -327,11 +424,11 @@ def main():
                     "workload": "%d GPUs x 1024 independent windows (10 keyframes, 2000 landmarks, ~14k observations), "
                                 "resident in HBM, no exchange on the data path" % world}}
     if rank == 0:
+        threads = min(16, os.cpu_count() or 1)
         if world == 1 and not args.no_secondary:
             dp.free()
-            result["secondary"] = secondary_measurements(solver)
+            result["secondary"] = secondary_measurements(solver, not args.no_cpu_baseline, threads)
         if world == 1 and not args.no_cpu_baseline:
-            threads = min(16, os.cpu_count() or 1)
             result["cpu_baseline"] = cpu_baseline(threads)
         print(json.dumps(result))
     if world > 1:

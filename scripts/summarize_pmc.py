@@ -41,7 +41,11 @@ def main():
         if fc.get(lead):
             out[v] = entry(sum(fa.get(m, 0.0) for m in members) / fc[lead], sum(wa.get(m, 0.0) for m in members) / max(wc.get(lead, 0), 1))
             out[v]["kernels"] = {m: entry(fa.get(m, 0.0) / fc[lead], wa.get(m, 0.0) / max(wc.get(lead, 0), 1)) for m in members if fc.get(m)}
-    json.dump(out, open(sys.argv[3], "w"), indent=1)
+    # stamped with the kernel sources and the workload the counters belong to: bench.py ignores the file otherwise
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import csrc_fingerprint
+    doc = {"csrc_sha256": csrc_fingerprint(), "workload": sys.argv[4] if len(sys.argv) > 4 else "", "kernels": out}
+    json.dump(doc, open(sys.argv[3], "w"), indent=1)
     print(json.dumps({k: v["hbm_bytes"] for k, v in out.items()}, indent=1))
 
 if __name__ == "__main__":

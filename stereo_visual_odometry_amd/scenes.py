@@ -188,6 +188,17 @@ def bal_scale(seed=3000, grid=(40, 50), n_points=1_000_000, degree=8, pitch=2.0,
     return prob, poses, points
 
 
+# Start of the benchmark's BAL-scale solve: far enough from the optimum (2 m, ~9 degrees, 3 m) that Levenberg-Marquardt
+# with Ceres' default tolerances is still descending after dozens of accepted steps, some trial steps are rejected
+# and the trust region has to work -- with the gentle default noise the same scene converges in two steps.
+HARD_START = dict(sigma_t=2.0, sigma_w=0.15, sigma_p=3.0)
+
+
+def bal_scale_hard(seed=3000, grid=(40, 50), n_points=1_000_000, **kw):
+    """bal_scale from a poor starting point (see HARD_START)."""
+    return bal_scale(seed=seed, grid=grid, n_points=n_points, **dict(HARD_START, **kw))
+
+
 def shard_by_point(prob, rank, world_size):
     """Landmark-aligned observation shard for multi-GPU solves: every rank keeps all poses and a
     contiguous block of the landmarks with all of their observations.  Landmarks of other ranks are

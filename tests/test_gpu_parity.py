@@ -374,6 +374,43 @@ def test_sharded_solve_equals_unsharded(oracle):
         assert np.abs(pts - ref.points[lo:hi]).max() <= 1e-7
 
 
+def test_c4_true_size_properties_and_two_rank_shards():
+    """BASELINE.json's BAL-scale configuration at its real size (2000 cameras x 1M landmarks x 8M observations),
+    where the oracle cannot follow: (1) with noise-free pixels the ground truth is a fixed point of (almost) zero
+    cost; (2) from the perturbed start the cost falls monotonically over accepted steps; (3) the matrix-core
+    Cholesky and block-Jacobi PCG reach the same point; (4) the same solve sharded by landmark over two ranks
+    (gathered elimination per shard, packed reduced matrix summed over ranks) reproduces the one-GPU solve."""
+    sv = hipba.Solver(0)
+    prob, gt_p, gt_q = scenes.bal_scale(seed=3000, n_points=1_000_000, pixel_sigma=0.0)
+    assert prob.obs_pose.shape[0] == 8_000_000 and prob.poses.shape[0] == 2000
+    ex = hipba.Problem(gt_p, gt_q, prob.obs_pose, prob.obs_point, prob.obs_uv, prob.K, prob.camera_model, prob.pose_const)
+    s = sv.solve(ex, hipba.default_options(max_num_iterations=2))
+    assert s["initial_cost"] < 1e-2 * ex.obs_pose.shape[0]  # float32-rounded pixels only
+    assert np.abs(ex.poses - gt_p).max() < 1e-4 and np.abs(ex.points - gt_q).max() < 1e-2
+    del ex
+    dp = sv.upload(prob)
+    o = hipba.default_options(max_num_iterations=3, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
+    a = dp.solve(o, log=True)[0]
+    costs = [it["cost"] for it in a["iterations"] if it["step_is_successful"]]
+    assert len(costs) >= 3 and all(c1 < c0 for c0, c1 in zip(costs, costs[1:])) and costs[-1] < 1e-2 * costs[0]
+    pa, qa = dp.download()
+    dp.reset()
+    o.linear_solver = hipba.LINEAR_PCG
+    o.pcg_max_iterations = 3000
+    b = dp.solve(o, log=True)[0]
+    pb, qb = dp.download()
+    dp.free(); sv.close()
+    assert abs(a["final_cost"] - b["final_cost"]) <= 1e-6 * a["final_cost"]
+    assert np.abs(pa - pb).max() <= 1e-6 and np.abs(qa - qb).max() <= 1e-5
+    del pb, qb
+    opts = lambda: hipba.default_options(max_num_iterations=3, function_tolerance=0.0, gradient_tolerance=0.0,
+                                         parameter_tolerance=0.0)
+    for r, (sr, poses, pts, lo, hi) in enumerate(run_threaded_ranks(prob, opts, timeout=600)):
+        assert sr["termination_type"] == a["termination_type"] and sr["num_iterations"] == a["num_iterations"]
+        assert abs(sr["final_cost"] - a["final_cost"]) <= 1e-9 * a["final_cost"]
+        assert np.abs(poses - pa).max() <= 1e-8 and np.abs(pts - qa[lo:hi]).max() <= 1e-7
+
+
 def test_sharded_solve_with_gathered_elimination_equals_unsharded():
     """The multi-GPU configuration of the BAL-scale problem in small: every shard is large enough (more than 20
     cameras, at least 2M observation pairs) for the per-block gather, whose blocks then go to the packed reduced
