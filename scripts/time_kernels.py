@@ -1,0 +1,21 @@
+"""Per-kernel durations (HIP events) on the benchmark's BAL-scale problem; prints one line per kernel.
+Usage: python scripts/time_kernels.py [n_points] [repeats]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from stereo_visual_odometry_amd import hipba, scenes
+
+n_points = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+rep = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+solver = hipba.Solver(0)
+prob, _, _ = scenes.bal_scale_hard(seed=3000, n_points=n_points)
+dp = solver.upload(prob)
+o = hipba.default_options(max_num_iterations=4)
+for k in range(6):
+    if k == hipba.KERNEL_REDUCED_SOLVE and "--solve" not in sys.argv:
+        continue
+    ms = dp.time_kernel(k, rep if k != hipba.KERNEL_REDUCED_SOLVE else 3, o)
+    print("%-18s %.4f ms" % (hipba.KERNEL_NAMES[k], ms))
+dp.reset()
+s = dp.solve(hipba.default_options(max_num_iterations=6), log=True)[0]
+print("6 LM iterations: %.2f ms, cost %.9e -> %.9e" % (1e3 * s["time_solve_s"], s["initial_cost"], s["final_cost"]))
+print(" ".join("%s%.6e" % ("+" if it["step_is_successful"] else "-", it["cost"]) for it in s["iterations"]))

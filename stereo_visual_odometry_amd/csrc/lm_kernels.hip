@@ -108,37 +108,80 @@ __device__ __forceinline__ double eval_obs(const CameraK& K, const LmParams& lm,
 // cost pass: 1/2 sum rho(|r|^2) per block (k_residual)
 //   which = 0: at x, 1: at the candidate.  blk_off selects the block range (active or CC).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_cost(DevP P, LmParams lm, int blk_off, int which, int ignore_active) {
-  __shared__ double red[8];
-  const int b = blockIdx.x + blk_off;
-  const BlockDesc d = P.blocks[b];
-  const WinState* st = P.ws + d.window;
-  if (!ignore_active && !st->active) return;
-  if (which == 1 && st->solve_failed) return;
-  const int sel = st->sel ^ which;
-  const CameraK K = P.wd[d.window].K;
-  double acc[2] = {0.0, 0.0};
+// A workgroup takes kCostGroup consecutive blocks, lane t the t-th observation of each: the index loads of all of
+// them are issued before the first gather and the gathers before the first multiply, so a wave has four
+// observations' memory round trips in flight instead of one (the pass is bound by those round trips, not by
+// arithmetic or bandwidth).  Partial sums stay one entry per block, summed in the same fixed order.
+constexpr int kCostGroup = 4;
+__global__ __launch_bounds__(kBlock) void k_cost(DevP P, LmParams lm, int blk_off, int blk_end, int which, int ignore_active) {
+  __shared__ double red[2 * kCostGroup * 4];
+  const int b0 = blk_off + blockIdx.x * kCostGroup;
   const int t = threadIdx.x;
-  if (t < d.n_obs) {
-    const long long o = d.obs_begin + t;
-    const double* pose = P.poses[sel] + 7ll * P.obs_pose[o];
-    const double* p = P.points[sel] + 3ll * P.obs_dp[o];
-    const double2 uv = reinterpret_cast<const double2*>(P.obs_uv)[o];
-    double r[2];
-    residual_only(K, pose, p, uv.x, uv.y, r);
-    const double s = r[0] * r[0] + r[1] * r[1];
-    double rho0 = s;
-    if (lm.loss == HIPBA_LOSS_HUBER) {
-      double f;
-      huber_correct(lm.loss_scale, s, &rho0, &f);
-    }
-    acc[0] = 0.5 * rho0;
-    acc[1] = isfinite(rho0) ? 0.0 : 1.0;
+  BlockDesc d[kCostGroup];
+  bool on[kCostGroup];
+  int sel[kCostGroup];
+  bool any = false;
+#pragma unroll
+  for (int k = 0; k < kCostGroup; ++k) {
+    on[k] = b0 + k < blk_end;
+    d[k] = P.blocks[on[k] ? b0 + k : b0];
   }
-  block_sum<2>(acc, red);
+#pragma unroll
+  for (int k = 0; k < kCostGroup; ++k) {
+    const WinState* st = P.ws + d[k].window;
+    if (on[k] && !ignore_active && !st->active) on[k] = false;
+    if (on[k] && which == 1 && st->solve_failed) on[k] = false;
+    sel[k] = st->sel ^ which;
+    any = any || on[k];
+  }
+  if (!any) return;
+  int ip[kCostGroup], iq[kCostGroup];
+  double2 uv[kCostGroup];
+  bool live[kCostGroup];
+#pragma unroll
+  for (int k = 0; k < kCostGroup; ++k) {
+    live[k] = on[k] && t < d[k].n_obs;
+    const long long o = d[k].obs_begin + (live[k] ? t : 0);
+    ip[k] = P.obs_pose[o];
+    iq[k] = P.obs_dp[o];
+    uv[k] = reinterpret_cast<const double2*>(P.obs_uv)[o];
+  }
+  double pose[kCostGroup][7], pt[kCostGroup][3];
+#pragma unroll
+  for (int k = 0; k < kCostGroup; ++k) {
+    const double* ps = P.poses[sel[k]] + 7ll * ip[k];
+    const double* p = P.points[sel[k]] + 3ll * iq[k];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) pose[k][i] = ps[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) pt[k][i] = p[i];
+  }
+  double acc[2 * kCostGroup];
+#pragma unroll
+  for (int k = 0; k < kCostGroup; ++k) {
+    acc[2 * k] = 0.0; acc[2 * k + 1] = 0.0;
+    if (live[k]) {
+      const CameraK K = P.wd[d[k].window].K;
+      double r[2];
+      residual_only(K, pose[k], pt[k], uv[k].x, uv[k].y, r);
+      const double s = r[0] * r[0] + r[1] * r[1];
+      double rho0 = s;
+      if (lm.loss == HIPBA_LOSS_HUBER) {
+        double f;
+        huber_correct(lm.loss_scale, s, &rho0, &f);
+      }
+      acc[2 * k] = 0.5 * rho0;
+      acc[2 * k + 1] = isfinite(rho0) ? 0.0 : 1.0;
+    }
+  }
+  block_sum<2 * kCostGroup>(acc, red);
   if (t == 0) {
-    P.partial[(long long)b * kPartialStride + 0] = acc[0];
-    P.partial[(long long)b * kPartialStride + 1] = acc[1];
+#pragma unroll
+    for (int k = 0; k < kCostGroup; ++k) {
+      if (!on[k]) continue;
+      P.partial[(long long)(b0 + k) * kPartialStride + 0] = acc[2 * k];
+      P.partial[(long long)(b0 + k) * kPartialStride + 1] = acc[2 * k + 1];
+    }
   }
 }
 
@@ -1744,7 +1787,8 @@ hipError_t launch_cost(const DevP& P, const LmParams& lm, int blk_off, int n_blk
   if (n_blk <= 0) return hipSuccess;
   DevP Q = P;
   if (second_bank) Q.partial = P.partial + ((long long)P.n_blk_pm + P.n_blk_vc + P.n_blk_cc) * kPartialStride;
-  hipLaunchKernelGGL(k_cost, dim3(n_blk), dim3(kBlock), 0, s, Q, lm, blk_off, which, ignore_active);
+  hipLaunchKernelGGL(k_cost, dim3((n_blk + kCostGroup - 1) / kCostGroup), dim3(kBlock), 0, s, Q, lm, blk_off,
+                     blk_off + n_blk, which, ignore_active);
   return hipGetLastError();
 }
 
