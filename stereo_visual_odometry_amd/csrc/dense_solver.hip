@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <vector>
 
 #include "hipba_internal.hpp"
 
@@ -40,6 +41,7 @@ size_t big_work_bytes(int n, int ncam) {
   b += rup(2 * npad * 8, 256);               // rhs, z
   b += rup((6 * npad + kPcgScalars + 3 * (size_t)ncam + 64) * 8, 256);  // pcg vectors + scalars + partials
   b += rup((size_t)36 * ncam * 8, 256);      // Minv
+  b += rup((npad / NB + 1) * sizeof(int), 256);  // first
   return b + 1024;
 }
 
@@ -52,7 +54,8 @@ void big_work_bind(BigWork& W, int n, int ncam, void* base) {
   W.LinvT = reinterpret_cast<double*>(p); p += rup((npad / NB) * NB * NB * 8, 256);
   W.rhs = reinterpret_cast<double*>(p); p += rup(2 * npad * 8, 256);
   W.pcg = reinterpret_cast<double*>(p); p += rup((6 * npad + kPcgScalars + 3 * (size_t)ncam + 64) * 8, 256);
-  W.Minv = reinterpret_cast<double*>(p);
+  W.Minv = reinterpret_cast<double*>(p); p += rup((size_t)36 * ncam * 8, 256);
+  W.first = reinterpret_cast<int*>(p);
 }
 
 // ---- packed blocks -> dense column-major lower ----------------------------------------------------
@@ -397,16 +400,20 @@ constexpr int LDT = 128 + 16;     // LDS row pitch (doubles): the two k-groups o
 // date itself and goes on to factor it (potrf_block): the next panel factorisation, one workgroup's work on the
 // critical path, runs beside this launch's other tiles instead of after them.
 constexpr size_t kGemmNtLds = (size_t)4 * KC * LDT * 8;
+// ENVELOPE (MODE 0): first[i] is the first tile column of tile row i that can be non-zero (monotone in i): of the
+// panel columns [kcol, kcol + K) a tile in row i needs only those from first[i] * NB on -- the factor is zero before
+// them.  Tile row m of the grid is the right-hand side (tile row rhs_tile of the matrix), which is dense.
 template <int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm_nt(DevP P, double* Amat, int ld, int i0, int j0, int kcol, int K,
                                                  const double* Linv, long long Linv_or_m, double* fuse_linv,
-                                                 double* fuse_linvt) {
+                                                 double* fuse_linvt, const int* first, int rhs_tile) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double (*sA)[KC * LDT] = reinterpret_cast<double (*)[KC * LDT]>(smem);                 // i-tile, two stages
   double (*sB)[KC * LDT] = reinterpret_cast<double (*)[KC * LDT]>(smem + 2 * KC * LDT);  // j-tile
   if (!P.ws[0].active || P.ws[0].solve_failed) return;
   if (MODE == 0 && fuse_linv && blockIdx.x == 0) {
-    potrf_block<true>(P, Amat, ld, i0, fuse_linv, fuse_linvt, smem, kcol, K);
+    const int skip = first ? max(0, first[i0] * NB - kcol) : 0;
+    potrf_block<true>(P, Amat, ld, i0, fuse_linv, fuse_linvt, smem, kcol + skip, K - skip);
     return;
   }
   int ti, tj;
@@ -426,7 +433,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     } else {
       r = m; c = id - tri;
     }
-    ti = i0 + r; tj = j0 + c;
+    ti = r == m ? rhs_tile : i0 + r; tj = j0 + c;
+    if (first && r != m) {
+      const int skip = first[ti] * NB - kcol;
+      if (skip > 0) { kcol += skip; K -= skip; }
+      if (K <= 0) return;
+    }
   } else {
     ti = i0 + blockIdx.x; tj = j0 + blockIdx.y;
   }
@@ -527,7 +539,7 @@ constexpr int kTrsmRows = 32;  // rows per workgroup of the panel solve: 32 -> t
 template <int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm_k128(DevP P, double* Amat, int ld, int i0, int j0, int kcol,
                                                      const double* Linv, double* fuse_linv, double* fuse_linvt,
-                                                     int row_tiles) {
+                                                     int row_tiles, int rhs_row0) {
   constexpr int TI = MODE == 0 ? 64 : kTrsmRows, TJ = MODE == 0 ? 64 : NB;
   constexpr int LDA = TI + 16, LDB = TJ + 16;
   constexpr int PA = TI / 16, PB = TJ / 16;    // doubles per thread and stage
@@ -543,7 +555,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       potrf_block<true>(P, Amat, ld, i0, fuse_linv, fuse_linvt, smem, kcol, NB);
     return;
   }
-  const int row0 = i0 * NB + blockIdx.x * TI;
+  // the row chunks of the panel's envelope, then one chunk of the right-hand side's tile row
+  const int row0 = (int)blockIdx.x == row_tiles - 1 ? rhs_row0 : i0 * NB + blockIdx.x * TI;
   const int col0 = MODE == 0 ? j0 * NB + blockIdx.y * TJ : 0;
   if (MODE == 0 && col0 > row0 + TI - 1) return;  // wholly above the diagonal
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -708,13 +721,13 @@ __global__ __launch_bounds__(kTrsvThreads) void k_trsv_first(DevP P, int k, cons
   trsv_solve_block(LinvT_all + (long long)k * NB * NB, zk, part, yk, y + k * NB);
 }
 
-__global__ __launch_bounds__(kTrsvThreads) void k_trsv_bwd(DevP P, const double* A, int ld, int k, const double* LinvT_all,
-                                                           double* z, double* y) {
+__global__ __launch_bounds__(kTrsvThreads) void k_trsv_bwd(DevP P, const double* A, int ld, int k, int j_first,
+                                                           const double* LinvT_all, double* z, double* y) {
   __shared__ double zk[NB];
   __shared__ double yk[NB];
   __shared__ double part[4][NB];
   const int t = threadIdx.x, r = t & (NB - 1), h = t >> 7;
-  const int j = blockIdx.x;  // 0 .. k-1
+  const int j = j_first + blockIdx.x;  // j_first .. k-1: the row blocks above k inside its envelope
   const bool last = j == k - 1;
   // The launch is one link of a chain of dependent launches, so every load that does not depend on another is
   // issued before anything waits: the tile of the factor, the inverse block the last workgroup needs, z and y.
@@ -793,10 +806,21 @@ hipError_t configure_dense_kernels() {
   return e;
 }
 
-hipError_t big_solve_cholesky(const DevP& P, const BigWork& W, hipStream_t s) {
+hipError_t big_solve_cholesky(const DevP& P, const BigWork& W, const int* h_first, hipStream_t s) {
   const int n = W.n, npad = W.npad, nt = npad / NB;
   const int ld = (int)dense_ld(npad);  // one extra tile row: b^T rides along as row npad (see k_pad_init)
   const int ncam = n / 6;
+  // Envelope of the factor by tiles (camera_order.hpp): first[i], monotone, <= i - 1; last[k] = the last tile row
+  // panel k reaches.  Without one the matrix is taken as dense.
+  std::vector<int> first(nt, 0), last(nt, nt - 1);
+  if (h_first) {
+    for (int i = 0; i < nt; ++i) first[i] = h_first[i];
+    for (int k = 0, i = 0; k < nt; ++k) {
+      while (i + 1 < nt && first[i + 1] <= k) ++i;
+      last[k] = i < k ? k : i;
+    }
+  }
+  const int* d_first = h_first ? W.first : nullptr;
   if (!P.dense_S)  // otherwise the elimination has written the blocks where they belong
     hipLaunchKernelGGL(k_unpack_lower, dim3((ncam * 36 + 255) / 256, ncam), dim3(256), 0, s, P, W.A, ld);
   hipLaunchKernelGGL(k_pad_init, dim3((npad + 255) / 256), dim3(256), 0, s, P, W.A, n, npad, ld);
@@ -807,35 +831,43 @@ hipError_t big_solve_cholesky(const DevP& P, const BigWork& W, hipStream_t s) {
   // Look-ahead by fusion: the workgroup that owns the next diagonal block in an update launch factors it right
   // there, so only the very first panel factorisation is a launch of its own.  (Overlapping through a second
   // stream was measured and lost 5 %: the panel kernels queue behind 50 us trailing-update workgroups.)
-  // Row tiles run to nt inclusive: tile row nt is the right-hand side.
+  // Every step covers the tile rows of its panel's envelope plus tile row nt, the right-hand side.
   // Block size: with the panel factorisations hidden in the narrow updates, wide blocks win -- measured at 94
   // panels: 8 -> 18.8 ms, 16 -> 17.7, 24 -> 17.7, 32 -> 17.0, 47 -> 19.3 (30 and 34-40: 18.3-19.1).
-  const int kOuter = nt >= 64 ? 32 : (nt >= 24 ? 16 : 8);
+  static const int outer_override = getenv("HIPBA_CHOL_OUTER") ? atoi(getenv("HIPBA_CHOL_OUTER")) : 0;
+  const int kOuter = outer_override > 0 ? outer_override : (nt >= 64 ? 32 : (nt >= 24 ? 16 : 8));
   hipLaunchKernelGGL(k_potrf_inv, dim3(1), dim3(256), kPotrfLds, s, P, W.A, ld, 0, W.Linv, W.LinvT);
   for (int p0 = 0; p0 < nt; p0 += kOuter) {
     const int p1 = p0 + kOuter < nt ? p0 + kOuter : nt;
     for (int p = p0; p < p1; ++p) {
-      hipLaunchKernelGGL(k_gemm_k128<1>, dim3((NB / kTrsmRows) * (nt - p - 1) + 1, 1), dim3(256), kLdsTrsm, s, P, W.A, ld, p + 1, 0,
+      const int rows = last[p] - p;  // tile rows below the diagonal block that panel p reaches
+      hipLaunchKernelGGL(k_gemm_k128<1>, dim3((NB / kTrsmRows) * rows + 1, 1), dim3(256), kLdsTrsm, s, P, W.A, ld, p + 1, 0,
                          p * NB, (const double*)(W.Linv + (long long)p * NB * NB), (double*)nullptr, (double*)nullptr,
-                         (NB / kTrsmRows) * (nt - p - 1) + 1);
-      if (p + 1 < p1)  // bring the block's remaining panel columns up to date with panel p (K = 128); factor p + 1
+                         (NB / kTrsmRows) * rows + 1, nt * NB);
+      if (p + 1 < p1) {  // bring the block's remaining panel columns up to date with panel p (K = 128); factor p + 1
         // grid.x padded to a multiple of 8: workgroups go to the 8 XCDs round-robin by linear index, so with
         // that width an XCD keeps the same row tiles for every column tile and finds their panel rows in its L2
-        hipLaunchKernelGGL(k_gemm_k128<0>, dim3((2 * (nt - p - 1) + 1 + 7) / 8 * 8, 2 * (p1 - p - 1)), dim3(256),
+        const int cols = (p1 - 1 < last[p] ? p1 - 1 : last[p]) - p;
+        hipLaunchKernelGGL(k_gemm_k128<0>, dim3((2 * rows + 1 + 7) / 8 * 8, 2 * cols), dim3(256),
                            kLdsK128Fused, s, P, W.A, ld, p + 1, p + 1, p * NB, (const double*)nullptr, W.Linv, W.LinvT,
-                           2 * (nt - p - 1) + 1);
+                           2 * rows + 1, nt * NB);
+      }
     }
-    const int rest = nt - p1;
-    if (rest > 0)  // trailing update with the whole block (K = kOuter * 128); factor panel p1
-      hipLaunchKernelGGL(k_gemm_nt<0>, dim3(rest * (rest + 1) / 2 + rest), dim3(256), kLdsNtFused, s, P, W.A, ld, p1, p1,
-                         p0 * NB, (p1 - p0) * NB, (const double*)nullptr, (long long)rest, W.Linv, W.LinvT);
+    if (p1 < nt) {  // trailing update with the whole block (K = kOuter * 128) inside its envelope; factor panel p1
+      const int m = last[p1 - 1] - p1 + 1;
+      hipLaunchKernelGGL(k_gemm_nt<0>, dim3(m * (m + 1) / 2 + m), dim3(256), kLdsNtFused, s, P, W.A, ld, p1, p1,
+                         p0 * NB, (p1 - p0) * NB, (const double*)nullptr, (long long)m, W.Linv, W.LinvT, d_first, nt);
+    }
   }
   double* z = W.rhs + npad;
   hipLaunchKernelGGL(k_extract_z, dim3((npad + 255) / 256), dim3(256), 0, s, P, (const double*)W.A, npad, ld, z);
   double* y = W.rhs;
   hipLaunchKernelGGL(k_trsv_first, dim3(1), dim3(kTrsvThreads), 0, s, P, nt - 1, (const double*)W.LinvT, (const double*)z, y);
-  for (int k = nt - 1; k >= 1; --k)
-    hipLaunchKernelGGL(k_trsv_bwd, dim3(k), dim3(kTrsvThreads), 0, s, P, (const double*)W.A, ld, k, (const double*)W.LinvT, z, y);
+  for (int k = nt - 1; k >= 1; --k) {
+    const int j0 = first[k] < k ? first[k] : k - 1;
+    hipLaunchKernelGGL(k_trsv_bwd, dim3(k - j0), dim3(kTrsvThreads), 0, s, P, (const double*)W.A, ld, k, j0,
+                       (const double*)W.LinvT, z, y);
+  }
   hipLaunchKernelGGL(k_store_solution, dim3((n + 255) / 256), dim3(256), 0, s, P, y, n);
   return hipGetLastError();
 }

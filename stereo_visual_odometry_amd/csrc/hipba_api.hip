@@ -25,6 +25,7 @@
 #include <thread>
 #include <vector>
 
+#include "camera_order.hpp"
 #include "hipba_internal.hpp"
 
 using namespace hipba;
@@ -198,6 +199,9 @@ struct hipba_device_problem_s {
   bool S_fully_written = false;  // gathered mode, every off-diagonal block has a pair: no word of S needs zeroing
   BigWork big;
   bool has_big = false;
+  // first tile column of every 128-row tile of the reduced matrix (camera_order.hpp): what the dense
+  // factorisation may skip.  A shard knows its own landmarks' couplings only: sharded solves merge these first.
+  std::vector<int> env_first;
   // end-of-solve snapshot in the handle's pinned staging buffer (small one-shot solves): the control words and both
   // parameter buffers, fetched with the solve's own final synchronisation so that reading the result back costs no
   // further round trip over the host link
@@ -315,8 +319,11 @@ int validate_problem(const hipba_problem& p, int w) {
 }
 
 // ---- analysis + upload -------------------------------------------------------------------------
+// pose_order (one-window problems, optional): the poses of the window in the order their blocks should take in the
+// reduced camera system (a permutation of 0 .. n_poses - 1; constant and unobserved ones are skipped).  Null: chosen
+// here (see camera_order.hpp).  Shards of one problem must all be given the same order.
 int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool use_handle_arena, int log_cap,
-                   bool all_poses_active, hipba_device_problem_s** out) {
+                   bool all_poses_active, hipba_device_problem_s** out, const int32_t* pose_order = nullptr) {
   for (int w = 0; w < nw; ++w) {
     int rc = validate_problem(probs[w], w);
     if (rc) return rc;
@@ -447,20 +454,70 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
       }
       R->meta[w].n_act_obs = 0;
     }
-    // sort each landmark's segment by pose index (stable) so that slots increase along a segment
-    for (int pp = 0; pp < n_pm_points; ++pp) {
-      const long long s0 = pp_start[pp], s1 = pp_start[pp + 1];
-      for (long long i = s0 + 1; i < s1; ++i) {
-        const int cp = obs_pose[i];
-        const double u = obs_uv[2 * i], v = obs_uv[2 * i + 1];
-        long long j = i - 1;
-        while (j >= s0 && obs_pose[j] > cp) {
-          obs_pose[j + 1] = obs_pose[j];
-          obs_uv[2 * (j + 1)] = obs_uv[2 * j]; obs_uv[2 * (j + 1) + 1] = obs_uv[2 * j + 1];
-          --j;
+  }
+
+  // ---- order of the poses in the reduced system (one large window: the dense factorisation's envelope) --------
+  const bool dense_path = nw == 1 && 6 * max_ncam > kSmallMaxN;
+  if (dense_path) {
+    const int ncam = n_slots;
+    const int n_tiles = (6 * ncam + kCholNB - 1) / kCholNB;
+    // co-visibility of the variable poses: two poses are coupled in S when they share a variable landmark
+    PoseGraph graph(ncam);
+    {
+      std::vector<int> seg;
+      for (int pp = 0; pp < n_pm_points; ++pp) {
+        seg.clear();
+        for (long long o = pp_start[pp]; o < pp_start[pp + 1]; ++o) {
+          const int g = pose_gslot[obs_pose[o]];
+          if (g >= 0 && std::find(seg.begin(), seg.end(), g) == seg.end()) seg.push_back(g);
         }
-        obs_pose[j + 1] = cp; obs_uv[2 * (j + 1)] = u; obs_uv[2 * (j + 1) + 1] = v;
+        for (size_t i = 0; i < seg.size(); ++i)
+          for (size_t j = i + 1; j < seg.size(); ++j) graph.connect(seg[i], seg[j]);
       }
+    }
+    std::vector<int> order(ncam);  // order[k] = old slot at position k
+    std::iota(order.begin(), order.end(), 0);
+    if (pose_order) {
+      std::vector<char> seen(probs[0].n_poses, 0);
+      int k = 0;
+      for (int i = 0; i < probs[0].n_poses; ++i) {
+        const int c = pose_order[i];
+        if (c < 0 || c >= probs[0].n_poses || seen[c])
+          return fail(HIPBA_ERR_INVALID_ARGUMENT, "pose_order is not a permutation of the window's poses (entry %d = %d)", i, c);
+        seen[c] = 1;
+        if (pose_gslot[c] >= 0) order[k++] = pose_gslot[c];
+      }
+    } else if (!all_poses_active) {
+      // natural order or reverse Cuthill-McKee, whichever leaves the factorisation less to do
+      double cost_id = 0.0, cost_rcm = 0.0;
+      tile_envelope(graph, order, kCholNB, n_tiles, &cost_id);
+      std::vector<int> rcm = reverse_cuthill_mckee(graph);
+      tile_envelope(graph, rcm, kCholNB, n_tiles, &cost_rcm);
+      if (cost_rcm < 0.9 * cost_id) order.swap(rcm);
+    }
+    R->env_first = tile_envelope(graph, order, kCholNB, n_tiles);
+    std::vector<int> new_slot(ncam);
+    for (int k = 0; k < ncam; ++k) new_slot[order[k]] = k;
+    for (long long c = 0; c < NP; ++c)
+      if (pose_gslot[c] >= 0) pose_gslot[c] = new_slot[pose_gslot[c]];
+    for (long long c = 0; c < NP; ++c)
+      if (pose_gslot[c] >= 0) slot_pose[pose_gslot[c]] = (int)c;
+  }
+  // sort each landmark's segment by slot (constant poses, slot -1, first; ties by pose index): the pair lists want
+  // slot_i <= slot_j for i < j, and repeated observations by one pose next to each other
+  for (int pp = 0; pp < n_pm_points; ++pp) {
+    const long long s0 = pp_start[pp], s1 = pp_start[pp + 1];
+    for (long long i = s0 + 1; i < s1; ++i) {
+      const int cp = obs_pose[i];
+      const long long key = ((long long)pose_gslot[cp] << 32) + cp;
+      const double u = obs_uv[2 * i], v = obs_uv[2 * i + 1];
+      long long j = i - 1;
+      while (j >= s0 && ((long long)pose_gslot[obs_pose[j]] << 32) + obs_pose[j] > key) {
+        obs_pose[j + 1] = obs_pose[j];
+        obs_uv[2 * (j + 1)] = obs_uv[2 * j]; obs_uv[2 * (j + 1) + 1] = obs_uv[2 * j + 1];
+        --j;
+      }
+      obs_pose[j + 1] = cp; obs_uv[2 * (j + 1)] = u; obs_uv[2 * (j + 1) + 1] = v;
     }
   }
 
@@ -924,6 +981,10 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   if (e == hipSuccess) e = hipMemcpyAsync(R->poses0, P.poses[0], poses.size() * 8, hipMemcpyDeviceToDevice, s);
   if (e == hipSuccess) e = hipMemcpyAsync(R->points0, P.points[0], points.size() * 8, hipMemcpyDeviceToDevice, s);
   if (e == hipSuccess) e = hipMemsetAsync(P.ws, 0, sizeof(WinState) * nw, s);
+  if (e == hipSuccess && R->has_big && !R->env_first.empty()) {
+    R->env_first.push_back(0);  // the right-hand side's tile row is dense
+    e = hipMemcpyAsync(R->big.first, R->env_first.data(), sizeof(int) * R->env_first.size(), hipMemcpyHostToDevice, s);
+  }
   if (e == hipSuccess) e = hipStreamSynchronize(s);  // staging is reused by the next call
   if (e != hipSuccess) return fail(HIPBA_ERR_HIP, "upload failed: %s", hipGetErrorString(e));
   *out = owner.release();
@@ -975,6 +1036,22 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
   do {                                                                                  \
     if (allreduce((buf), (n), (op))) return fail(HIPBA_ERR_COMM, "all-reduce callback failed"); \
   } while (0)
+
+  // The dense factorisation skips what lies outside the envelope of the reduced matrix.  A shard knows the couplings
+  // of its own landmarks only: the ranks merge their envelopes (element-wise minimum of the first tile columns)
+  // before the first factorisation.
+  bool env_ready = R->has_big && !R->env_first.empty();
+  if (env_ready && sharded) {
+    const size_t nt1 = R->env_first.size();
+    std::vector<double> neg(nt1);
+    for (size_t i = 0; i < nt1; ++i) neg[i] = -(double)R->env_first[i];
+    HIPBA_HIP(hipMemcpyAsync(P.yc, neg.data(), sizeof(double) * nt1, hipMemcpyHostToDevice, s));
+    AR(P.yc, nt1, HIPBA_REDUCE_MAX);
+    HIPBA_HIP(hipMemcpyAsync(neg.data(), P.yc, sizeof(double) * nt1, hipMemcpyDeviceToHost, s));
+    HIPBA_HIP(hipStreamSynchronize(s));
+    for (size_t i = 0; i < nt1; ++i) R->env_first[i] = (int)(-neg[i]);
+    HIPBA_HIP(hipMemcpyAsync(R->big.first, R->env_first.data(), sizeof(int) * nt1, hipMemcpyHostToDevice, s));
+  }
 
   // iteration 0: cost at the starting point, fixed cost, Jacobi scaling
   HIPBA_HIP(launch_cost(P, lm, 0, n_act_blk, 0, 1, false, s));
@@ -1055,7 +1132,7 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
       } else if (solver == HIPBA_LINEAR_PCG) {
         HIPBA_HIP(big_solve_pcg(P, R->big, o.pcg_max_iterations, o.pcg_tolerance, s));
       } else {
-        HIPBA_HIP(big_solve_cholesky(P, R->big, s));
+        HIPBA_HIP(big_solve_cholesky(P, R->big, env_ready ? R->env_first.data() : nullptr, s));
       }
     }
     HIPBA_HIP(launch_backsub(P, lm, s));
@@ -1564,7 +1641,7 @@ int hipba_time_kernel(hipba_handle h, hipba_device_problem dp, const hipba_optio
     auto solve_once = [&]() -> int {
       if (small) HIPBA_HIP(launch_window_solve_small(P, lm, max_n, 0, s));
       else if (o.linear_solver == HIPBA_LINEAR_PCG) HIPBA_HIP(big_solve_pcg(P, dp->big, o.pcg_max_iterations, o.pcg_tolerance, s));
-      else HIPBA_HIP(big_solve_cholesky(P, dp->big, s));
+      else HIPBA_HIP(big_solve_cholesky(P, dp->big, dp->env_first.empty() ? nullptr : dp->env_first.data(), s));
       return HIPBA_OK;
     };
     int rc = prepare();

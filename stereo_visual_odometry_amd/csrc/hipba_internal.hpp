@@ -44,13 +44,15 @@ struct BigWork {
   double* rhs = nullptr;   // [npad]
   double* pcg = nullptr;   // PCG vectors and scalars
   double* Minv = nullptr;  // [36 * ncam] block-Jacobi preconditioner
+  int* first = nullptr;    // [npad/NB + 1] first tile column of every tile row of the factor's envelope
   size_t bytes() const;
 };
 constexpr int kCholNB = 128;
 size_t big_work_bytes(int n, int ncam);
 void big_work_bind(BigWork& W, int n, int ncam, void* base);
 // Cholesky: S (packed, P.S) y = b (P.b) -> P.yc; marks ws.solve_failed when S is not positive definite
-hipError_t big_solve_cholesky(const DevP& P, const BigWork& W, hipStream_t s);
+// h_first: the envelope (host copy of W.first, camera_order.hpp), or null for a dense factorisation
+hipError_t big_solve_cholesky(const DevP& P, const BigWork& W, const int* h_first, hipStream_t s);
 // zeroes the lower triangle of W.A: for solves whose elimination writes the blocks of S straight into it (DevP::dense_S)
 hipError_t big_zero_lower(const DevP& P, const BigWork& W, hipStream_t s);
 // block-Jacobi preconditioned conjugate gradients on the packed S
