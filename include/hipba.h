@@ -251,9 +251,20 @@ int hipba_upload(hipba_handle h, int32_t n_windows, const hipba_problem* problem
  * Upload ONE window's shard for hipba_solve_device_sharded: all poses of the window (identical on
  * every rank) and this rank's landmarks with all of their observations.  Unlike hipba_upload every
  * non-constant pose takes part in the reduced system even if this rank holds none of its
- * observations, so that all ranks lay the reduced camera matrix out identically.
+ * observations, so that all ranks lay the reduced camera matrix out identically.  pose_order: see
+ * hipba_pose_order below.
  */
-int hipba_upload_shard(hipba_handle h, const hipba_problem* shard, hipba_device_problem* out);
+int hipba_upload_shard(hipba_handle h, const hipba_problem* shard, const int32_t* pose_order,
+                       hipba_device_problem* out);
+/*
+ * The order in which hipba_upload would lay the poses of a one-window problem out in the reduced camera system
+ * (what Ceres' ordering step does for SPARSE_NORMAL_CHOLESKY, optimizer.cpp:55): co-visible poses next to each
+ * other, so that the dense factorisation can skip the part of the matrix that stays zero.  order [n_poses]
+ * receives a permutation of the pose indices.  A caller that shards a problem computes it ONCE on the whole
+ * problem and hands the same order to every rank's hipba_upload_shard (pose_order; NULL keeps the natural order):
+ * a shard sees the couplings of its own landmarks only and cannot choose for the others.
+ */
+int hipba_pose_order(const hipba_problem* problem, int32_t* order);
 /* restore the parameters uploaded by hipba_upload (device-to-device copy) */
 int hipba_reset(hipba_handle h, hipba_device_problem dp);
 /* LM on the resident problem; summaries [n_windows] */
@@ -272,6 +283,22 @@ int hipba_download(hipba_handle h, hipba_device_problem dp, int32_t window, doub
                    double* points);
 int hipba_free_problem(hipba_handle h, hipba_device_problem dp);
 
+/* ---- native RCCL communicator for sharded solves ------------------------------------------ */
+/*
+ * A hipba_comm whose all-reduce is ncclAllReduce (RCCL over xGMI) queued on the engine's stream: for C / C++
+ * callers of hipba_solve_device_sharded (the reference is C++, src/solve/optimizer.cpp), one process per GPU.
+ * Rank 0 asks for an id and hands the 128 bytes to the other ranks by whatever means the job has (MPI, a file, a
+ * socket); then every rank calls hipba_rccl_comm_create (collective: it returns when all ranks have called it).
+ * RCCL is loaded with dlopen on first use; HIPBA_ERR_COMM if it is not there or a call fails.
+ */
+#define HIPBA_RCCL_ID_BYTES 128
+int hipba_rccl_get_unique_id(uint8_t id[HIPBA_RCCL_ID_BYTES]);
+int hipba_rccl_comm_create(int device, const uint8_t id[HIPBA_RCCL_ID_BYTES], int32_t rank, int32_t world_size,
+                           hipba_comm* out);
+/* all-reduce calls made through comm so far and the bytes they carried */
+int hipba_rccl_comm_stats(const hipba_comm* comm, int64_t* calls, int64_t* bytes);
+int hipba_rccl_comm_destroy(hipba_comm* comm);
+
 /* ---- measurement hooks (bench / profiling; no counterpart in the reference) ------------- */
 enum {
   HIPBA_KERNEL_RESIDUAL = 0,          /* cost pass                                  */
@@ -287,6 +314,12 @@ enum {
  * state and returns the average duration of one launch in milliseconds measured
  * with HIP events on the handle's stream.  Does not change the parameters.
  */
+/*
+ * Floating-point operations of one Cholesky factorisation of the resident problem's largest reduced camera
+ * system: as a dense matrix ((6 n_c)^3 / 3), and inside the envelope the library's pose order leaves (what the
+ * factorisation actually has to do; equal to the dense figure for windows solved in LDS or without an envelope).
+ */
+int hipba_reduced_solve_flops(hipba_device_problem dp, double* flops_dense, double* flops_envelope);
 int hipba_time_kernel(hipba_handle h, hipba_device_problem dp, const hipba_options* options,
                       int32_t kernel, int32_t repeats, double* avg_ms);
 

@@ -487,6 +487,7 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
         seen[c] = 1;
         if (pose_gslot[c] >= 0) order[k++] = pose_gslot[c];
       }
+      if (k != ncam) return fail(HIPBA_ERR_INVALID_ARGUMENT, "pose_order lists %d of the %d variable poses", k, ncam);
     } else if (!all_poses_active) {
       // natural order or reverse Cuthill-McKee, whichever leaves the factorisation less to do
       double cost_id = 0.0, cost_rcm = 0.0;
@@ -1428,12 +1429,64 @@ int hipba_upload(hipba_handle h, int32_t n_windows, const hipba_problem* problem
   });
 }
 
-int hipba_upload_shard(hipba_handle h, const hipba_problem* shard, hipba_device_problem* out) {
+int hipba_pose_order(const hipba_problem* p, int32_t* order) {
+  return guarded([&]() -> int {
+    if (!p || !order) return fail(HIPBA_ERR_INVALID_ARGUMENT, "null argument");
+    int rc = validate_problem(*p, 0);
+    if (rc) return rc;
+    const int np = p->n_poses;
+    // variable poses that see a variable landmark, numbered in pose order
+    std::vector<int> node(np, -1);
+    std::vector<long long> start((size_t)p->n_points + 1, 0);
+    for (long long k = 0; k < p->n_obs; ++k) start[p->obs_point[k] + 1]++;
+    for (int i = 0; i < p->n_points; ++i) start[i + 1] += start[i];
+    std::vector<int> by_point((size_t)std::max<long long>(p->n_obs, 1));
+    {
+      std::vector<long long> cur(start.begin(), start.end() - 1);
+      for (long long k = 0; k < p->n_obs; ++k) by_point[cur[p->obs_point[k]]++] = p->obs_pose[k];
+    }
+    int n_nodes = 0;
+    for (int c = 0; c < np; ++c)
+      if (!(p->pose_const && p->pose_const[c])) node[c] = n_nodes++;
+    PoseGraph graph(std::max(n_nodes, 1));
+    std::vector<int> seg;
+    for (int q = 0; q < p->n_points; ++q) {
+      if (p->point_const && p->point_const[q]) continue;
+      seg.clear();
+      for (long long o = start[q]; o < start[q + 1]; ++o) {
+        const int g = node[by_point[o]];
+        if (g >= 0 && std::find(seg.begin(), seg.end(), g) == seg.end()) seg.push_back(g);
+      }
+      for (size_t i = 0; i < seg.size(); ++i)
+        for (size_t j = i + 1; j < seg.size(); ++j) graph.connect(seg[i], seg[j]);
+    }
+    std::vector<int> ord(n_nodes);
+    std::iota(ord.begin(), ord.end(), 0);
+    if (n_nodes > 1) {
+      const int n_tiles = (6 * n_nodes + kCholNB - 1) / kCholNB;
+      double cost_id = 0.0, cost_rcm = 0.0;
+      tile_envelope(graph, ord, kCholNB, n_tiles, &cost_id);
+      std::vector<int> rcm = reverse_cuthill_mckee(graph);
+      tile_envelope(graph, rcm, kCholNB, n_tiles, &cost_rcm);
+      if (cost_rcm < 0.9 * cost_id) ord.swap(rcm);
+    }
+    std::vector<int> pose_of(n_nodes);
+    for (int c = 0; c < np; ++c)
+      if (node[c] >= 0) pose_of[node[c]] = c;
+    int k = 0;
+    for (int i = 0; i < n_nodes; ++i) order[k++] = pose_of[ord[i]];
+    for (int c = 0; c < np; ++c)
+      if (node[c] < 0) order[k++] = c;
+    return HIPBA_OK;
+  });
+}
+
+int hipba_upload_shard(hipba_handle h, const hipba_problem* shard, const int32_t* pose_order, hipba_device_problem* out) {
   return guarded([&]() -> int {
     if (!h || !shard || !out) return fail(HIPBA_ERR_INVALID_ARGUMENT, "null argument");
     HIPBA_HIP(hipSetDevice(h->device));
     hipba_device_problem_s* R = nullptr;
-    int rc = build_resident(h, 1, shard, false, 301, true, &R);
+    int rc = build_resident(h, 1, shard, false, 301, true, &R, pose_order);
     if (rc) return rc;
     *out = R;
     return HIPBA_OK;
@@ -1601,6 +1654,30 @@ int hipba_evaluate_device(hipba_handle h, int32_t n_poses, const double* d_poses
     HIPBA_HIP(launch_residual_jacobian(K, make_lm(o), apply_loss, n_obs, n_poses, n_points, d_poses, d_points, d_obs_pose,
                                        d_obs_point, d_obs_uv, d_residuals, d_jac_pose, d_jac_point,
                                        d_cost ? h->eval_scratch : nullptr, d_cost, s));
+    return HIPBA_OK;
+  });
+}
+
+int hipba_reduced_solve_flops(hipba_device_problem dp, double* flops_dense, double* flops_envelope) {
+  return guarded([&]() -> int {
+    if (!dp) return fail(HIPBA_ERR_INVALID_ARGUMENT, "null argument");
+    const double n = 6.0 * dp->max_ncam;
+    const double dense = n * n * n / 3.0;
+    double env = dense;
+    if (dp->has_big && !dp->env_first.empty()) {
+      // tile products (128^3 multiply-adds each) of a factorisation that stays inside the envelope: an off-diagonal
+      // tile of row i takes one per tile between the row's first column and its own, plus half a product for its
+      // triangular solve; the diagonal tile half of that (symmetric) plus a sixth for its own factorisation
+      const int nt = (int)dp->env_first.size() - 1;  // the last entry belongs to the right-hand side's tile row
+      double prod = 0.0;
+      for (int i = 0; i < nt; ++i) {
+        const double w = i - dp->env_first[i] + 1;
+        prod += (w - 1) * (w - 2) / 2 + (w - 1) / 2 + (w - 1) * 0.5 + 1.0 / 6.0;
+      }
+      env = std::min(dense, prod * 2.0 * kCholNB * kCholNB * kCholNB);
+    }
+    if (flops_dense) *flops_dense = dense;
+    if (flops_envelope) *flops_envelope = env;
     return HIPBA_OK;
   });
 }

@@ -94,9 +94,50 @@ class CComm(C.Structure):
 # every symbol include/hipba.h declares
 EXPORTED_SYMBOLS = [
     "hipba_version", "hipba_last_error", "hipba_options_default", "hipba_create", "hipba_destroy", "hipba_stream",
-    "hipba_solve", "hipba_solve_batched", "hipba_evaluate", "hipba_evaluate_device", "hipba_upload", "hipba_upload_shard", "hipba_reset", "hipba_solve_device",
-    "hipba_solve_device_sharded", "hipba_download", "hipba_free_problem", "hipba_time_kernel",
+    "hipba_solve", "hipba_solve_batched", "hipba_evaluate", "hipba_evaluate_device", "hipba_upload", "hipba_upload_shard", "hipba_pose_order", "hipba_reset", "hipba_solve_device",
+    "hipba_solve_device_sharded", "hipba_download", "hipba_free_problem", "hipba_time_kernel", "hipba_reduced_solve_flops",
+    "hipba_rccl_get_unique_id", "hipba_rccl_comm_create", "hipba_rccl_comm_stats", "hipba_rccl_comm_destroy",
 ]
+
+
+RCCL_ID_BYTES = 128
+
+
+class RcclComm:
+    """hipba_comm over a native RCCL communicator (hipba_rccl_comm_create): the all-reduces of a sharded solve are
+    ncclAllReduce calls made by the library itself on the engine's stream -- no Python in the loop.  Rank 0 makes the
+    id (RcclComm.unique_id()) and the job distributes it (e.g. torch.distributed.broadcast_object_list)."""
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(RCCL_ID_BYTES)
+        _check(load_library().hipba_rccl_get_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, device, unique_id, rank, world_size):
+        self._lib = load_library()
+        self.c = CComm()
+        self.rank, self.world_size = int(rank), int(world_size)
+        rc = self._lib.hipba_rccl_comm_create(int(device), unique_id, self.rank, self.world_size, C.byref(self.c))
+        if rc != OK:
+            raise HipbaError(rc, "hipba_rccl_comm_create failed (is librccl.so loadable?)")
+
+    def _stat(self, which):
+        calls, nbytes = C.c_int64(0), C.c_int64(0)
+        self._lib.hipba_rccl_comm_stats(C.byref(self.c), C.byref(calls), C.byref(nbytes))
+        return (calls.value, nbytes.value)[which]
+
+    @property
+    def calls(self):
+        return self._stat(0)
+
+    @property
+    def bytes(self):
+        return self._stat(1)
+
+    def close(self):
+        if self.c.ctx:
+            self._lib.hipba_rccl_comm_destroy(C.byref(self.c))
 
 
 class HipbaError(RuntimeError):
@@ -137,7 +178,8 @@ def load_library(path=None):
                                           C.c_double, C.c_int32, C.POINTER(COptions), C.c_int, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p]
     lib.hipba_upload.argtypes = [C.c_void_p, C.c_int32, C.POINTER(CProblem), C.POINTER(C.c_void_p)]
-    lib.hipba_upload_shard.argtypes = [C.c_void_p, C.POINTER(CProblem), C.POINTER(C.c_void_p)]
+    lib.hipba_upload_shard.argtypes = [C.c_void_p, C.POINTER(CProblem), _ip, C.POINTER(C.c_void_p)]
+    lib.hipba_pose_order.argtypes = [C.POINTER(CProblem), _ip]
     lib.hipba_reset.argtypes = [C.c_void_p, C.c_void_p]
     lib.hipba_solve_device.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(COptions), C.POINTER(CSummary)]
     lib.hipba_solve_device_sharded.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(CComm), C.POINTER(COptions),
@@ -145,6 +187,11 @@ def load_library(path=None):
     lib.hipba_download.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, _dp, _dp]
     lib.hipba_free_problem.argtypes = [C.c_void_p, C.c_void_p]
     lib.hipba_time_kernel.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(COptions), C.c_int32, C.c_int32, _dp]
+    lib.hipba_reduced_solve_flops.argtypes = [C.c_void_p, _dp, _dp]
+    lib.hipba_rccl_get_unique_id.argtypes = [C.c_char_p]
+    lib.hipba_rccl_comm_create.argtypes = [C.c_int, C.c_char_p, C.c_int32, C.c_int32, C.POINTER(CComm)]
+    lib.hipba_rccl_comm_stats.argtypes = [C.POINTER(CComm), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    lib.hipba_rccl_comm_destroy.argtypes = [C.POINTER(CComm)]
     for name in EXPORTED_SYMBOLS:
         getattr(lib, name)  # AttributeError if the library lacks a declared entry point
     if path is None:
@@ -220,13 +267,15 @@ def _summary_dict(s, log=None):
 class DeviceProblem:
     """Windows resident in HBM (hipba_upload)."""
 
-    def __init__(self, solver, problems, shard=False):
+    def __init__(self, solver, problems, shard=False, pose_order=None):
         self.solver = solver
         self.problems = list(problems)
         arr = (CProblem * len(self.problems))(*[p.c() for p in self.problems])
         self._h = C.c_void_p()
         if shard:
-            _check(solver._lib.hipba_upload_shard(solver._h, arr, C.byref(self._h)))
+            po = None if pose_order is None else np.ascontiguousarray(pose_order, dtype=np.int32)
+            _check(solver._lib.hipba_upload_shard(solver._h, arr, None if po is None else po.ctypes.data_as(_ip),
+                                                  C.byref(self._h)))
         else:
             _check(solver._lib.hipba_upload(solver._h, len(self.problems), arr, C.byref(self._h)))
 
@@ -272,6 +321,12 @@ class DeviceProblem:
         _check(self.solver._lib.hipba_time_kernel(self.solver._h, self._h, C.byref(o), kernel, repeats,
                                                   C.cast(C.byref(ms), _dp)))
         return ms.value
+
+    def reduced_solve_flops(self):
+        """(dense, inside the envelope): flops of one factorisation of the reduced camera system"""
+        a, b = C.c_double(0.0), C.c_double(0.0)
+        _check(self.solver._lib.hipba_reduced_solve_flops(self._h, C.cast(C.byref(a), _dp), C.cast(C.byref(b), _dp)))
+        return a.value, b.value
 
     def free(self):
         if self._h:
@@ -358,5 +413,14 @@ class Solver:
             problems = [problems]
         return DeviceProblem(self, problems)
 
-    def upload_shard(self, shard):
-        return DeviceProblem(self, [shard], shard=True)
+    def upload_shard(self, shard, pose_order=None):
+        return DeviceProblem(self, [shard], shard=True, pose_order=pose_order)
+
+
+def pose_order(problem):
+    """hipba_pose_order: the order of the poses in the reduced camera system hipba_upload would choose for this
+    (whole) problem; hand it to every rank's upload_shard."""
+    out = np.zeros(problem.poses.shape[0], dtype=np.int32)
+    cp = problem.c()
+    _check(load_library().hipba_pose_order(C.byref(cp), out.ctypes.data_as(_ip)))
+    return out

@@ -76,7 +76,9 @@ class ShardedProblem:
         self.comm = comm
         self.full = problem
         self.shard, (self.lo, self.hi) = shard_by_point(problem, comm.rank, comm.world_size)
-        self.dp = solver.upload_shard(self.shard)
+        # the order of the poses in the reduced system is chosen on the whole problem (every rank has it here and
+        # computes the same order); a shard alone only knows its own landmarks' couplings
+        self.dp = solver.upload_shard(self.shard, hipba.pose_order(problem))
 
     def reset(self):
         self.dp.reset()

@@ -131,3 +131,22 @@ def test_cpp_harness_is_built_and_links_the_c_abi():
     assert os.path.exists(exe), "run ./build.sh"
     out = subprocess.run([exe, "--help"], capture_output=True, text=True)
     assert out.returncode == 0 and "usage: ba_test" in out.stdout
+
+
+def test_pose_order_is_a_permutation_and_keeps_a_keyframe_sequence_in_order():
+    # host-only entry point: no GPU needed.  A sliding window is banded in its natural order already; a camera
+    # grid whose co-visibility runs along the fast index is not
+    w, _, _ = scenes.kitti_like_window(1000, n_frames=40)
+    o = hipba.pose_order(w)
+    assert sorted(o.tolist()) == list(range(40))
+    assert o[:39].tolist() == list(range(1, 40)) and o[39] == 0   # variable poses in order, the constant one last
+    b, _, _ = scenes.bal_scale(n_points=20000, grid=(12, 30))
+    ob = hipba.pose_order(b)
+    assert sorted(ob.tolist()) == list(range(360)) and ob[-1] == 0
+    # under the chosen order co-visible poses are closer together than under the natural one
+    pos = np.empty(360, dtype=np.int64); pos[ob] = np.arange(360)
+    cam = b.obs_pose.reshape(-1, 8)
+    cam = cam[(cam != 0).all(axis=1)]
+    spread_natural = (cam.max(axis=1) - cam.min(axis=1)).max()
+    spread_ordered = (pos[cam].max(axis=1) - pos[cam].min(axis=1)).max()
+    assert spread_ordered < 0.75 * spread_natural
