@@ -40,7 +40,7 @@ enum {
   HIPBA_ERR_NO_DEVICE = -2,        /* no usable gfx950 device: there is no CPU fallback */
   HIPBA_ERR_HIP = -3,              /* a HIP runtime call failed */
   HIPBA_ERR_OUT_OF_MEMORY = -4,
-  HIPBA_ERR_UNSUPPORTED = -5,      /* e.g. a landmark with more than HIPBA_MAX_POINT_DEGREE observations */
+  HIPBA_ERR_UNSUPPORTED = -5,      /* e.g. a batched window of more than 32 variable poses */
   HIPBA_ERR_COMM = -6,             /* the caller's all-reduce callback failed */
   HIPBA_ERR_INTERNAL = -7          /* an unexpected C++ exception was caught at the boundary */
 };
@@ -54,6 +54,10 @@ enum { HIPBA_LINEAR_AUTO = 0, HIPBA_LINEAR_DENSE_CHOLESKY = 1, HIPBA_LINEAR_PCG 
 /* ceres::TerminationType */
 enum { HIPBA_CONVERGENCE = 0, HIPBA_NO_CONVERGENCE = 1, HIPBA_FAILURE = 2 };
 
+/* A landmark may have any number of observations (the reference adds one residual block per feature,
+   optimizer.cpp:37-51) in a single window of more than 20 variable poses; in smaller or batched windows a
+   landmark is limited to this many (more: HIPBA_ERR_UNSUPPORTED) -- with at most 32 poses in such a window that
+   only excludes a pose observing one landmark many times over. */
 #define HIPBA_MAX_POINT_DEGREE 256
 
 /*

@@ -39,7 +39,18 @@ struct BlockDesc {
   int n_runs;
   int window;
   int kind;              // 0 = PM, 1 = VC, 2 = CC
-  int pad;
+  int pad;               // PM: 0, or 1 + the index of the LongDesc whose landmark this block is a piece of
+};
+
+// A landmark with more observations than one block holds (the reference adds any number of residual blocks per
+// landmark, src/solve/optimizer.cpp:37-51): its observations fill a run of blocks of their own, and one workgroup
+// (k_long_point) walks them all for the sums the other landmarks form inside one block.
+struct LongDesc {
+  long long obs_begin;
+  int n_obs;
+  int pp;          // device landmark index
+  int blk_begin;   // its blocks: blk_begin .. blk_begin + n_blk - 1
+  int n_blk;
 };
 
 // a run: consecutive entries of a block's pair list that go to the same 6x6 block of the reduced matrix
@@ -123,6 +134,8 @@ struct DevP {
   const double* obs_uv;       // [2*]
   const long long* pp_obs_start;  // [n_pm_points+1]
   const BlockDesc* blocks;
+  const LongDesc* longs;          // landmarks longer than a block (gathered elimination only)
+  int n_long;
   const unsigned short* pairs;    // low byte = lane i, high byte = lane j, slot_i <= slot_j
   const RunDesc* runs;            // pair lists cut into runs of one destination (absent in staged mode)
   // gathered accumulation of the reduced matrix (one large window): every 6x6 block of S sums the products of

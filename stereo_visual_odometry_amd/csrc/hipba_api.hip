@@ -366,16 +366,14 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   std::vector<int> dp_of(NPT, -1);
   std::vector<WinDesc> wd(nw);
   int n_pm_points = 0;
+  bool has_long = false;
   for (int w = 0; w < nw; ++w) {
     wd[w] = WinDesc{};
     wd[w].pp_begin = n_pm_points;
     for (int i = 0; i < probs[w].n_points; ++i) {
       const long long gp = pt_base[w] + i;
       if (deg[gp] > 0) {
-        if (deg[gp] > HIPBA_MAX_POINT_DEGREE) {
-          return fail(HIPBA_ERR_UNSUPPORTED, "window %d: landmark %d has %d observations (limit %d)", w, i, deg[gp],
-                      HIPBA_MAX_POINT_DEGREE);
-        }
+        if (deg[gp] > kBlock) has_long = true;  // walks its observations block by block (see LongDesc)
         dp_of[gp] = n_pm_points++;
       }
     }
@@ -528,7 +526,8 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   // The pair list of a block: (i, j), i <= j, over the observations of each of its landmarks whose poses are
   // variable.  Only the sizes are fixed here (every list 16-byte aligned: blocks load them as uint4); the lists are
   // written further down, already in the order the accumulation mode wants.
-  long long pairs_total = 0;
+  long long pairs_total = 0, pairs_all = 0;
+  std::vector<LongDesc> longs;
   for (int w = 0; w < nw; ++w) {
     wd[w].pm_blk_begin = (int)blocks.size();
     int pp = wd[w].pp_begin;
@@ -540,6 +539,30 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
       d.window = w;
       d.kind = 0;
       int n = 0, np = 0;
+      if (pp_start[pp + 1] - pp_start[pp] > kBlock) {
+        // a landmark with more observations than a block holds: a run of blocks of its own, flagged with the index
+        // (+1) of its LongDesc; the per-landmark kernels leave those blocks to k_long_point
+        LongDesc L{};
+        L.obs_begin = pp_start[pp];
+        L.n_obs = (int)(pp_start[pp + 1] - pp_start[pp]);
+        L.pp = pp;
+        L.blk_begin = (int)blocks.size();
+        for (int left = L.n_obs; left > 0; left -= kBlock) {
+          BlockDesc e = d;
+          e.obs_begin = L.obs_begin + (L.n_obs - left);
+          e.n_obs = std::min(left, kBlock);
+          e.n_pairs = 0;
+          e.pad = (int)longs.size() + 1;
+          blocks.push_back(e);
+        }
+        L.n_blk = (int)blocks.size() - L.blk_begin;
+        longs.push_back(L);
+        long long v = 0;
+        for (long long o = pp_start[pp]; o < pp_start[pp + 1]; ++o) v += pose_gslot[obs_pose[o]] >= 0;
+        pairs_all += v * (v + 1) / 2;
+        ++pp;
+        continue;
+      }
       while (pp < wd[w].pp_end && n + (int)(pp_start[pp + 1] - pp_start[pp]) <= kBlock) {
         const int s1 = n + (int)(pp_start[pp + 1] - pp_start[pp]);
         int v = 0;
@@ -559,6 +582,7 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
       d.n_obs = n;
       d.n_pairs = np;
       pairs_total += np;
+      pairs_all += np;
       blocks.push_back(d);
     }
     wd[w].pm_blk_end = (int)blocks.size();
@@ -624,26 +648,36 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   // every block of S sum its own products, each recomputed from the landmark's record and the two poses.
   std::vector<uint2> pair_obs, pair_pt;
   std::vector<long long> chunk_start;
-  const bool staged = nw == 1 && max_ncam > 20 && max_ncam <= 0xffff && pairs.size() >= (size_t)2000000 &&
-                      n_pm_obs < 0xffffffffll;
+  const bool can_stage = nw == 1 && max_ncam > 20 && max_ncam <= 0xffff && n_pm_obs < 0xffffffffll;
+  if (has_long && !can_stage)
+    return fail(HIPBA_ERR_UNSUPPORTED, "a landmark with more than %d observations needs a single window of more than 20 "
+                "variable poses (the gathered elimination); this call has %d window(s), at most %d variable poses", kBlock,
+                nw, max_ncam);
+  const bool staged = can_stage && (has_long || pairs_all + 8 >= 2000000);
   if (staged) {
-    for (const BlockDesc& d : blocks)
-      if (d.kind == 0) generate_pairs(d);
+    // every pair (i, j), i <= j, of the observations of a landmark by variable poses, straight from the landmark's
+    // segment (blocks play no part here, so a landmark may be as long as it likes); two observations by the SAME
+    // pose go to a diagonal block, which needs the product in both orders
     const int ncam = wd[0].ncam;
+    const int cam_base = wd[0].cam_base;
     const long long n_dest = (long long)ncam * (ncam + 1) / 2;
     std::vector<long long> dest_start(n_dest + 1, 0);
-    std::vector<long long> dest_of(pairs.size());
-    for (const BlockDesc& d : blocks) {
-      if (d.kind != 0) continue;
-      for (int q = 0; q < d.n_pairs; ++q) {
-        const unsigned short pr = pairs[d.pair_begin + q];
-        const int si = pose_gslot[obs_pose[d.obs_begin + (pr & 0xff)]] - wd[0].cam_base;
-        const int sj = pose_gslot[obs_pose[d.obs_begin + (pr >> 8)]] - wd[0].cam_base;
-        const long long dst = tri_index(si, sj, ncam);
-        dest_of[d.pair_begin + q] = dst;
-        dest_start[dst + 1]++;
+    auto for_each_pair = [&](auto&& f) {
+      for (int pp = 0; pp < n_pm_points; ++pp) {
+        for (long long oi = pp_start[pp]; oi < pp_start[pp + 1]; ++oi) {
+          const int si = pose_gslot[obs_pose[oi]] - cam_base;
+          if (si < 0) continue;
+          const long long row = tri_index(si, si, ncam) - si;
+          for (long long oj = oi; oj < pp_start[pp + 1]; ++oj) {
+            const int sj = pose_gslot[obs_pose[oj]] - cam_base;
+            if (sj < 0) continue;
+            f(pp, oi, oj, si, sj, row + sj);
+            if (oj > oi && sj == si) f(pp, oj, oi, si, sj, row + sj);
+          }
+        }
       }
-    }
+    };
+    for_each_pair([&](int, long long, long long, int, int, long long dst) { dest_start[dst + 1]++; });
     {
       // the gather stores every off-diagonal block that has a pair and the initialisation every diagonal one
       bool all = true;
@@ -654,18 +688,11 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
     std::vector<long long> cur(dest_start.begin(), dest_start.end() - 1);
     pair_obs.resize((size_t)dest_start[n_dest]);
     pair_pt.resize(pair_obs.size());
-    for (const BlockDesc& d : blocks) {
-      if (d.kind != 0) continue;
-      for (int q = 0; q < d.n_pairs; ++q) {
-        const unsigned short pr = pairs[d.pair_begin + q];
-        const long long oi = d.obs_begin + (pr & 0xff), oj = d.obs_begin + (pr >> 8);
-        const unsigned si = (unsigned)(pose_gslot[obs_pose[oi]] - wd[0].cam_base);
-        const unsigned sj = (unsigned)(pose_gslot[obs_pose[oj]] - wd[0].cam_base);
-        const long long at = cur[dest_of[d.pair_begin + q]]++;
-        pair_obs[at] = make_uint2((unsigned)oi, (unsigned)oj);
-        pair_pt[at] = make_uint2((unsigned)obs_dp[oi], (si << 16) | sj);
-      }
-    }
+    for_each_pair([&](int pp, long long oi, long long oj, int si, int sj, long long dst) {
+      const long long at = cur[dst]++;
+      pair_obs[at] = make_uint2((unsigned)oi, (unsigned)oj);
+      pair_pt[at] = make_uint2((unsigned)pp, ((unsigned)si << 16) | (unsigned)sj);
+    });
     // one wave per chunk of about kGatherChunk pairs; a chunk holds whole destinations, so every block of S
     // has exactly one writer
     // (begin, end) per chunk, longest first: a diagonal block alone has as many pairs as its camera has
@@ -891,6 +918,8 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   up.add(&d_wd, wd.size());
   up.add(&d_runs, std::max<size_t>(runs.size(), 1));
   if (staged) { up.add(&d_pair_obs, pair_obs.size()); up.add(&d_pair_pt, pair_pt.size()); up.add(&d_chunk_start, chunk_start.size()); }
+  LongDesc* d_longs = nullptr;
+  up.add(&d_longs, std::max<size_t>(longs.size(), 1));
   const size_t upload_bytes = up.total;
   R->upload_bytes = (long long)upload_bytes;
   ArenaPlan work = up;  // continues after the uploaded region
@@ -970,6 +999,8 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   stage(d_pairs, pairs.data(), pairs.size() * 2);
   stage(d_wd, wd.data(), wd.size() * sizeof(WinDesc));
   stage(d_runs, runs.data(), runs.size() * sizeof(RunDesc));
+  stage(d_longs, longs.data(), longs.size() * sizeof(LongDesc));
+  P.longs = d_longs; P.n_long = (int)longs.size();
   if (staged) {
     stage(d_pair_obs, pair_obs.data(), pair_obs.size() * sizeof(uint2));
     stage(d_pair_pt, pair_pt.data(), pair_pt.size() * sizeof(uint2));

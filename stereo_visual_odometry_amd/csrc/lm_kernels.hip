@@ -379,7 +379,7 @@ __global__ __launch_bounds__(kBlock) void k_point_colnorm(DevP P, LmParams lm) {
   __shared__ double sh[kBlock * 3];
   const BlockDesc d = P.blocks[blockIdx.x];
   const WinState* st = P.ws + d.window;
-  if (!st->active) return;
+  if (!st->active || d.pad) return;  // (a piece of a long landmark: k_long_point's)
   const int sel = st->sel;
   const CameraK K = P.wd[d.window].K;
   const int t = threadIdx.x;
@@ -568,6 +568,7 @@ __global__ __launch_bounds__(kBlock) void k_point_schur(DevP P, LmParams lm, int
 
   for (; blk < blk_end; blk += blk_step) {
     const BlockDesc d = P.blocks[blk];
+    if (MODE == 2 && d.pad) return;  // a piece of a long landmark (gathered mode only): k_long_point's
     if (SMALL) __syncthreads();  // accumulators zeroed / previous block's products read
     HIPBA_TICK(1);
     // the block's pair and run lists go to LDS when they fit; the loads are issued here, ahead of the
@@ -970,6 +971,7 @@ __global__ __launch_bounds__(kBlock) void k_backsub(DevP P, LmParams lm) {
   const int w = d.window;
   const WinState* st = P.ws + w;
   if (!st->active || st->solve_failed) return;
+  if (d.kind == 0 && d.pad) return;  // a piece of a long landmark: k_long_point's
   const WinDesc wd = P.wd[w];
   const int sel = st->sel;
   const int t = threadIdx.x;
@@ -1041,6 +1043,167 @@ __global__ __launch_bounds__(kBlock) void k_backsub(DevP P, LmParams lm) {
   if (t == 0) {
     double* pr = P.partial + (long long)b * kPartialStride;
     pr[0] = acc[0]; pr[1] = acc[1]; pr[2] = acc[2];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Landmarks with more observations than a block holds (LongDesc): one workgroup per landmark walks all of its
+// observations, 256 at a time, and does for it what the block kernels do for the others.
+//   PHASE 0  Jacobi column scaling (k_point_colnorm)
+//   PHASE 1  V, g_p, V^-1, the landmark's record, robust weights (k_point_schur<2>: gathered elimination only,
+//            the pair products themselves come from the global pair list)
+//   PHASE 2  back-substitution, candidate landmark, model-cost-change terms (k_backsub)
+// Sums run over the lanes' strided partial sums in a fixed order.
+// ------------------------------------------------------------------------------------------
+template <int PHASE>
+__global__ __launch_bounds__(kBlock) void k_long_point(DevP P, LmParams lm) {
+  __shared__ double red[9 * 4];
+  __shared__ double bc[4];
+  const LongDesc L = P.longs[blockIdx.x];
+  const BlockDesc d0 = P.blocks[L.blk_begin];
+  const int w = d0.window;
+  const WinState* st = P.ws + w;
+  if (!st->active) return;
+  if (PHASE == 2 && st->solve_failed) return;
+  const WinDesc wd = P.wd[w];
+  const int sel = st->sel;
+  const int t = threadIdx.x, pp = L.pp;
+  const double p[3] = {P.points[sel][3ll * pp], P.points[sel][3ll * pp + 1], P.points[sel][3ll * pp + 2]};
+  if (PHASE == 0) {
+    double n[3] = {0.0, 0.0, 0.0};
+    for (int k = t; k < L.n_obs; k += kBlock) {
+      const long long o = L.obs_begin + k;
+      const double2 uv = reinterpret_cast<const double2*>(P.obs_uv)[o];
+      double r[2], Jc[12], Jp[6];
+      eval_obs<true>(wd.K, lm, P.poses[sel] + 7ll * P.obs_pose[o], p, uv.x, uv.y, nullptr, nullptr, r, Jc, Jp);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) n[i] += Jp[i] * Jp[i] + Jp[3 + i] * Jp[3 + i];
+    }
+    block_sum<3>(n, red);
+    if (t == 0) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) P.scale_p[3ll * pp + i] = lm.jacobi_scaling ? 1.0 / (1.0 + sqrt(n[i])) : 1.0;
+    }
+    return;
+  }
+  const double sp[3] = {P.scale_p[3ll * pp], P.scale_p[3ll * pp + 1], P.scale_p[3ll * pp + 2]};
+  if (PHASE == 1) {
+    double a[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) a[i] = 0.0;
+    for (int k = t; k < L.n_obs; k += kBlock) {
+      const long long o = L.obs_begin + k;
+      const int g = P.pose_gslot[P.obs_pose[o]];
+      const double2 uv = reinterpret_cast<const double2*>(P.obs_uv)[o];
+      double r[2], Jc[12], Jp[6], lf = 1.0;
+      eval_obs<true>(wd.K, lm, P.poses[sel] + 7ll * P.obs_pose[o], p, uv.x, uv.y, g < 0 ? nullptr : P.scale_c + 6ll * g, sp,
+                     r, Jc, Jp, &lf);
+      if (lm.loss != HIPBA_LOSS_NONE && P.fw) P.fw[o] = lf;
+      a[0] += Jp[0] * Jp[0] + Jp[3] * Jp[3];
+      a[1] += Jp[0] * Jp[1] + Jp[3] * Jp[4];
+      a[2] += Jp[0] * Jp[2] + Jp[3] * Jp[5];
+      a[3] += Jp[1] * Jp[1] + Jp[4] * Jp[4];
+      a[4] += Jp[1] * Jp[2] + Jp[4] * Jp[5];
+      a[5] += Jp[2] * Jp[2] + Jp[5] * Jp[5];
+      a[6] += Jp[0] * r[0] + Jp[3] * r[1];
+      a[7] += Jp[1] * r[0] + Jp[4] * r[1];
+      a[8] += Jp[2] * r[0] + Jp[5] * r[1];
+    }
+    block_sum<9>(a, red);
+    if (t == 0) {
+      const double inv_radius = 1.0 / st->radius;
+      double V[6] = {a[0], a[1], a[2], a[3], a[4], a[5]};
+      V[0] += fmin(fmax(V[0], lm.min_lm_diagonal), lm.max_lm_diagonal) * inv_radius;
+      V[3] += fmin(fmax(V[3], lm.min_lm_diagonal), lm.max_lm_diagonal) * inv_radius;
+      V[5] += fmin(fmax(V[5], lm.min_lm_diagonal), lm.max_lm_diagonal) * inv_radius;
+      double Vi[6];
+      inv3_sym(V, Vi);
+      double gmax = 0.0, g2 = 0.0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) P.Vinv[6ll * pp + i] = Vi[i];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        P.gp[3ll * pp + i] = a[6 + i];
+        const double gu = a[6 + i] / sp[i];
+        gmax = fmax(gmax, fabs(gu));
+        g2 += gu * gu;
+      }
+      // the landmark's share of the gradient norms is reported under its first block
+      for (int b = 0; b < L.n_blk; ++b) {
+        P.gpart[2ll * (L.blk_begin + b)] = b == 0 ? gmax : 0.0;
+        P.gpart[2ll * (L.blk_begin + b) + 1] = b == 0 ? g2 : 0.0;
+      }
+      if (P.prec) {
+        double* rec = P.prec + 16ll * pp;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { rec[i] = p[i]; rec[3 + i] = sp[i]; }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) rec[6 + i] = Vi[i];
+        rec[12] = sp[0] * (Vi[0] * a[6] + Vi[1] * a[7] + Vi[2] * a[8]);
+        rec[13] = sp[1] * (Vi[1] * a[6] + Vi[3] * a[7] + Vi[4] * a[8]);
+        rec[14] = sp[2] * (Vi[2] * a[6] + Vi[4] * a[7] + Vi[5] * a[8]);
+        rec[15] = 0.0;
+      }
+    }
+    return;
+  }
+  // PHASE 2: W^T y_c summed over the landmark, then the per-observation model terms with the landmark's step
+  double wy[3] = {0.0, 0.0, 0.0};
+  for (int k = t; k < L.n_obs; k += kBlock) {
+    const long long o = L.obs_begin + k;
+    const int g = P.pose_gslot[P.obs_pose[o]];
+    if (g < 0) continue;
+    const double2 uv = reinterpret_cast<const double2*>(P.obs_uv)[o];
+    double r[2], Jc[12], Jp[6];
+    eval_obs<true>(wd.K, lm, P.poses[sel] + 7ll * P.obs_pose[o], p, uv.x, uv.y, P.scale_c + 6ll * g, sp, r, Jc, Jp);
+    double mc0 = 0.0, mc1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { mc0 -= Jc[i] * P.yc[6ll * g + i]; mc1 -= Jc[6 + i] * P.yc[6ll * g + i]; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) wy[i] += -(Jp[i] * mc0 + Jp[3 + i] * mc1);
+  }
+  block_sum<3>(wy, red);
+  if (t == 0) { bc[0] = wy[0]; bc[1] = wy[1]; bc[2] = wy[2]; }
+  __syncthreads();
+  const double tt[3] = {P.gp[3ll * pp] - bc[0], P.gp[3ll * pp + 1] - bc[1], P.gp[3ll * pp + 2] - bc[2]};
+  const double* Vi = P.Vinv + 6ll * pp;
+  double stp[3];  // step_p = -y_p
+  stp[0] = -(Vi[0] * tt[0] + Vi[1] * tt[1] + Vi[2] * tt[2]);
+  stp[1] = -(Vi[1] * tt[0] + Vi[3] * tt[1] + Vi[4] * tt[2]);
+  stp[2] = -(Vi[2] * tt[0] + Vi[4] * tt[1] + Vi[5] * tt[2]);
+  double acc[3] = {0.0, 0.0, 0.0};
+  for (int k = t; k < L.n_obs; k += kBlock) {
+    const long long o = L.obs_begin + k;
+    const int g = P.pose_gslot[P.obs_pose[o]];
+    const double2 uv = reinterpret_cast<const double2*>(P.obs_uv)[o];
+    double r[2], Jc[12], Jp[6];
+    eval_obs<true>(wd.K, lm, P.poses[sel] + 7ll * P.obs_pose[o], p, uv.x, uv.y, g < 0 ? nullptr : P.scale_c + 6ll * g, sp, r,
+                   Jc, Jp);
+    double m0 = Jp[0] * stp[0] + Jp[1] * stp[1] + Jp[2] * stp[2];
+    double m1 = Jp[3] * stp[0] + Jp[4] * stp[1] + Jp[5] * stp[2];
+    if (g >= 0) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) { m0 -= Jc[i] * P.yc[6ll * g + i]; m1 -= Jc[6 + i] * P.yc[6ll * g + i]; }
+    }
+    acc[0] += m0 * (r[0] + m0 / 2.0) + m1 * (r[1] + m1 / 2.0);
+  }
+  if (t == 0) {
+    double* xc = P.points[sel ^ 1] + 3ll * pp;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const double xn = p[i] + stp[i] * sp[i];
+      xc[i] = xn;
+      const double df = p[i] - xn;
+      acc[1] += df * df;
+      acc[2] += p[i] * p[i];
+    }
+  }
+  block_sum<3>(acc, red);
+  if (t == 0) {
+    for (int b = 0; b < L.n_blk; ++b) {
+      double* pr = P.partial + (long long)(L.blk_begin + b) * kPartialStride;
+      pr[0] = b == 0 ? acc[0] : 0.0; pr[1] = b == 0 ? acc[1] : 0.0; pr[2] = b == 0 ? acc[2] : 0.0;
+    }
   }
 }
 
@@ -1807,6 +1970,7 @@ hipError_t launch_make_scale_c(const DevP& P, int jacobi, hipStream_t s) {
 hipError_t launch_point_colnorm(const DevP& P, const LmParams& lm, hipStream_t s) {
   if (P.n_blk_pm <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_point_colnorm, dim3(P.n_blk_pm), dim3(kBlock), 0, s, P, lm);
+  if (P.n_long > 0) hipLaunchKernelGGL(k_long_point<0>, dim3(P.n_long), dim3(kBlock), 0, s, P, lm);
   return hipGetLastError();
 }
 
@@ -1820,6 +1984,7 @@ hipError_t launch_point_schur(const DevP& P, const LmParams& lm, int small_ncam,
   if (P.n_blk_pm <= 0) return hipSuccess;
   if (P.prec) {
     hipLaunchKernelGGL(k_point_schur<2>, dim3(P.n_blk_pm), dim3(kBlock), schur_lds_bytes(0, true), s, P, lm, 1);
+    if (P.n_long > 0) hipLaunchKernelGGL(k_long_point<1>, dim3(P.n_long), dim3(kBlock), 0, s, P, lm);
     const size_t gather_lds = (size_t)(kBlock / 64) * kGatherLds * 8;
     const unsigned grid = (unsigned)((P.n_chunks + kBlock / 64 - 1) / (kBlock / 64));
     if (grid) hipLaunchKernelGGL(k_schur_gather, dim3(grid), dim3(kBlock), gather_lds, s, P, lm);
@@ -1854,6 +2019,7 @@ hipError_t launch_backsub(const DevP& P, const LmParams& lm, hipStream_t s) {
   const int nb = P.n_blk_pm + P.n_blk_vc;
   if (nb <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_backsub, dim3(nb), dim3(kBlock), 0, s, P, lm);
+  if (P.n_long > 0) hipLaunchKernelGGL(k_long_point<2>, dim3(P.n_long), dim3(kBlock), 0, s, P, lm);
   return hipGetLastError();
 }
 

@@ -540,6 +540,44 @@ def test_gathered_elimination_with_constant_poses_and_landmarks(solver, oracle):
     assert np.array_equal(g.points[point_const == 1], prob.points[point_const == 1])
 
 
+@pytest.mark.parametrize("loss", [None, "huber"])
+def test_landmark_with_a_thousand_observations(solver, oracle, loss):
+    """The reference adds one residual block per feature with no limit per landmark (optimizer.cpp:37-51).  One
+    landmark here is observed ten times by each of a hundred cameras (1000 residual blocks, every pair of them a
+    product in the reduced matrix, repeated poses included); the elimination kernels work on 256-observation blocks,
+    so this landmark is walked by a workgroup of its own."""
+    prob, gt_p, gt_q = scenes.bal_scale(seed=41, grid=(10, 10), n_points=20000, depth_lo=5.0, depth_hi=30.0)
+    rng = np.random.default_rng(5)
+    far = np.array([9.0, 9.0, 35.0])
+    cams = np.repeat(np.arange(100, dtype=np.int32), 10)
+    pc = scenes._to_camera(gt_p[cams], np.broadcast_to(far, (1000, 3)))
+    uv = (scenes._project_z(pc) + rng.normal(0.0, 0.5, (1000, 2))).astype(np.float32).astype(np.float64)
+    big = hipba.Problem(prob.poses, np.vstack([prob.points, far + rng.normal(0.0, 0.1, 3)]),
+                        np.concatenate([prob.obs_pose, cams]),
+                        np.concatenate([prob.obs_point, np.full(1000, 20000, dtype=np.int32)]),
+                        np.vstack([prob.obs_uv, uv]), prob.K, prob.camera_model, prob.pose_const, None)
+    kw, okw = {}, {}
+    if loss == "huber":
+        kw = dict(loss=hipba.LOSS_HUBER, loss_scale=0.6)
+        okw = dict(loss=oracle.LOSS_HUBER, loss_scale=0.6)
+    g = big.copy()
+    s = solver.solve(g, hipba.default_options(max_num_iterations=6, **kw))
+    o = to_oracle(oracle, big)
+    so, oits = oracle.solve(o, oracle.default_options(max_num_iterations=6, jacobian_mode=oracle.JAC_ANALYTIC, num_threads=8, **okw))
+    assert s["termination_type"] == so["termination_type"]
+    assert abs(s["final_cost"] - so["final_cost"]) <= RTOL_COST * so["final_cost"]
+    assert np.abs(g.poses - o.poses).max() <= ATOL_STATE and np.abs(g.points - o.points).max() <= ATOL_STATE
+    assert_logs_match(s["iterations"], oits)
+    # small and batched windows keep the per-block limit, and say so
+    w, _, _ = scenes.small_window(7, n_frames=4, n_points=30)
+    many = hipba.Problem(w.poses, w.points, np.concatenate([w.obs_pose, np.full(300, 1, dtype=np.int32)]),
+                         np.concatenate([w.obs_point, np.zeros(300, dtype=np.int32)]),
+                         np.vstack([w.obs_uv, np.tile(w.obs_uv[:1], (300, 1))]), w.K, w.camera_model, w.pose_const, None)
+    with pytest.raises(hipba.HipbaError) as ex:
+        solver.solve(many)
+    assert ex.value.code == hipba.ERR_UNSUPPORTED and "observations" in str(ex.value)
+
+
 def _check_against_oracle(oracle, prob, gpu_prob, summary, loss=None, loss_scale=1.0, max_iter=300):
     o = to_oracle(oracle, prob)
     kw = dict(max_num_iterations=max_iter, jacobian_mode=oracle.JAC_ANALYTIC, num_threads=8)
