@@ -26,3 +26,5 @@ g++ -O2 -std=c++17 -Wall -pthread -Iinclude -I$SRC/host -o $OUT/ba_stage_demo $S
 echo "built $OUT/ba_stage_demo"
 g++ -O2 -std=c++17 -Wall -Iinclude -I$SRC/host -o $OUT/kitti_info $SRC/host/kitti_info_cli.cpp
 echo "built $OUT/kitti_info"
+g++ -O2 -std=c++17 -Wall -pthread -Iinclude -I$SRC/host -o $OUT/ba_sequences $SRC/host/ba_sequences_cli.cpp -L$OUT -lhipba -Wl,-rpath,'$ORIGIN'
+echo "built $OUT/ba_sequences"

@@ -194,6 +194,8 @@ const char* hipba_last_error(void);
 void hipba_options_default(hipba_options* options);
 
 /* ---- handle: owns the device, one stream and grow-only device buffers ------------------- */
+/* number of visible GPUs (for callers that spread handles over them; HIPBA_ERR_NO_DEVICE if there is none) */
+int hipba_device_count(int* count);
 int hipba_create(int device, hipba_handle* out);
 int hipba_destroy(hipba_handle h);
 /* hipStream_t of the handle, for callers that order their own work (or a collective) on it */

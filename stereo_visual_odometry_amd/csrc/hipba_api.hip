@@ -1363,6 +1363,19 @@ void hipba_options_default(hipba_options* o) {
   o->minimizer_progress_to_stdout = 0;
 }
 
+int hipba_device_count(int* count) {
+  return guarded([&]() -> int {
+    if (!count) return fail(HIPBA_ERR_INVALID_ARGUMENT, "count is null");
+    *count = 0;
+    int n = 0;
+    const hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+      return fail(HIPBA_ERR_NO_DEVICE, "no HIP device available (%s)", e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    *count = n;
+    return HIPBA_OK;
+  });
+}
+
 int hipba_create(int device, hipba_handle* out) {
   return guarded([&]() -> int {
     if (!out) return fail(HIPBA_ERR_INVALID_ARGUMENT, "out is null");

@@ -93,7 +93,7 @@ class CComm(C.Structure):
 
 # every symbol include/hipba.h declares
 EXPORTED_SYMBOLS = [
-    "hipba_version", "hipba_last_error", "hipba_options_default", "hipba_create", "hipba_destroy", "hipba_stream",
+    "hipba_version", "hipba_last_error", "hipba_options_default", "hipba_device_count", "hipba_create", "hipba_destroy", "hipba_stream",
     "hipba_solve", "hipba_solve_batched", "hipba_evaluate", "hipba_evaluate_device", "hipba_upload", "hipba_upload_shard", "hipba_pose_order", "hipba_reset", "hipba_solve_device",
     "hipba_solve_device_sharded", "hipba_download", "hipba_free_problem", "hipba_time_kernel", "hipba_reduced_solve_flops",
     "hipba_rccl_get_unique_id", "hipba_rccl_comm_create", "hipba_rccl_comm_stats", "hipba_rccl_comm_destroy",

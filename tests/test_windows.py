@@ -228,3 +228,22 @@ def test_stage_demo_bundle_adjustment_reduces_drift_and_dumps_replayable_windows
     assert r.returncode == 0, r.stderr
     f = r.stdout.split()
     assert float(f[f.index("final_cost") + 1]) == pytest.approx(s["final_cost"], rel=1e-9)
+
+
+@pytest.mark.gpu
+def test_concurrent_sequences_runner():
+    """Eleven sequences at once, one host thread + engine handle + bundle-adjustment stage each, devices assigned
+    round-robin (one here): the replay form of "KITTI 00-10 across the GPUs" -- the frontend's image work is a stated
+    sleep, everything from the map bookkeeping to the solve is real."""
+    exe = os.path.join(LIB, "ba_sequences")
+    r = subprocess.run([exe, "--sequences", "11", "--frames", "60", "--window", "20", "--frontend-ms", "2"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    f = r.stdout.split()
+    v = {k: float(f[f.index(k) + 1]) for k in ("sequences", "devices", "windows_solved", "frontend_stub_ms",
+                                                "frame_latency_ms_p50", "frame_latency_ms_p95", "ba_frame_ms_p50",
+                                                "ba_frame_ms_max", "frames_per_s")}
+    assert v["sequences"] == 11 and v["devices"] >= 1 and v["frontend_stub_ms"] == 2.0
+    assert v["windows_solved"] == 11 * 2          # frames 20 and 40 of every sequence (frontend.cpp:71)
+    assert 2.0 <= v["frame_latency_ms_p50"] < 20.0  # the stub plus map bookkeeping
+    assert v["ba_frame_ms_p50"] > 0.5 and v["ba_frame_ms_max"] < 2000.0
