@@ -42,6 +42,7 @@ size_t big_work_bytes(int n, int ncam) {
   b += rup((6 * npad + kPcgScalars + 3 * (size_t)ncam + 64) * 8, 256);  // pcg vectors + scalars + partials
   b += rup((size_t)36 * ncam * 8, 256);      // Minv
   b += rup((npad / NB + 1) * sizeof(int), 256);  // first
+  b += 256;                                      // sync
   return b + 1024;
 }
 
@@ -55,7 +56,8 @@ void big_work_bind(BigWork& W, int n, int ncam, void* base) {
   W.rhs = reinterpret_cast<double*>(p); p += rup(2 * npad * 8, 256);
   W.pcg = reinterpret_cast<double*>(p); p += rup((6 * npad + kPcgScalars + 3 * (size_t)ncam + 64) * 8, 256);
   W.Minv = reinterpret_cast<double*>(p); p += rup((size_t)36 * ncam * 8, 256);
-  W.first = reinterpret_cast<int*>(p);
+  W.first = reinterpret_cast<int*>(p); p += rup((npad / NB + 1) * sizeof(int), 256);
+  W.sync = reinterpret_cast<unsigned*>(p);
 }
 
 // ---- packed blocks -> dense column-major lower ----------------------------------------------------
@@ -89,9 +91,10 @@ hipError_t big_zero_lower(const DevP& P, const BigWork& W, hipStream_t s) {
 // rows beyond n: identity on the padded diagonal, and b^T as row npad -- the first row of one extra tile row.
 // Factorising [S; b^T] row-wise like any other row block leaves z^T = (L^-1 b)^T in that row: the forward
 // substitution costs no launches of its own.
-__global__ void k_pad_init(DevP P, double* A, int n, int npad, int ld) {
+__global__ void k_pad_init(DevP P, double* A, int n, int npad, int ld, unsigned* sync) {
   if (!P.ws[0].active) return;
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col == 0) *sync = 0u;  // arrivals of the diagonal-block hand-offs of this factorisation (k_gemm_k128)
   if (col >= npad) return;
   for (int row = n; row < ld; ++row) A[(long long)col * ld + row] = (row == col) ? 1.0 : 0.0;
   if (col < n) A[(long long)col * ld + npad] = P.b[6ll * P.wd[0].cam_base + col];
@@ -539,7 +542,7 @@ constexpr int kTrsmRows = 32;  // rows per workgroup of the panel solve: 32 -> t
 template <int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm_k128(DevP P, double* Amat, int ld, int i0, int j0, int kcol,
                                                      const double* Linv, double* fuse_linv, double* fuse_linvt,
-                                                     int row_tiles, int rhs_row0) {
+                                                     int row_tiles, int rhs_row0, unsigned* sync, unsigned sync_target) {
   constexpr int TI = MODE == 0 ? 64 : kTrsmRows, TJ = MODE == 0 ? 64 : NB;
   constexpr int LDA = TI + 16, LDB = TJ + 16;
   constexpr int PA = TI / 16, PB = TJ / 16;    // doubles per thread and stage
@@ -550,11 +553,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   double (*sA)[KC * LDA] = reinterpret_cast<double (*)[KC * LDA]>(smem);
   double (*sB)[KC * LDB] = reinterpret_cast<double (*)[KC * LDB]>(smem + 2 * KC * LDA);
   if ((int)blockIdx.x >= row_tiles) return;  // padding of the grid width
-  if (MODE == 0 && fuse_linv && blockIdx.x < 2 && blockIdx.y < 2) {
-    if (blockIdx.x == 0 && blockIdx.y == 0 && P.ws[0].active && !P.ws[0].solve_failed)
-      potrf_block<true>(P, Amat, ld, i0, fuse_linv, fuse_linvt, smem, kcol, NB);
-    return;
-  }
+  // FUSE: the three 64x64 tiles of the diagonal block (i0, i0) are updated like any other tile, by workgroups
+  // (0,0), (1,0) and (1,1); the last two then signal, and (0,0) waits for them and factors the block.
+  const bool diag_part = MODE == 0 && fuse_linv && blockIdx.x < 2 && blockIdx.y < 2;
   // the row chunks of the panel's envelope, then one chunk of the right-hand side's tile row
   const int row0 = (int)blockIdx.x == row_tiles - 1 ? rhs_row0 : i0 * NB + blockIdx.x * TI;
   const int col0 = MODE == 0 ? j0 * NB + blockIdx.y * TJ : 0;
@@ -644,6 +645,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         else *dst = acc[a][b][r];
       }
     }
+  }
+  if (MODE == 0 && diag_part) {
+    // Hand-off of the diagonal block's tiles inside the launch.  Producers: every storing wave drains its stores,
+    // the workgroup meets, one lane releases at agent scope and counts itself in.  Consumer (0,0): drains its own
+    // stores, one lane polls the counter (bounded), acquires at agent scope (which also drops this CU's L1 lines of
+    // the block), the workgroup meets, and the factorisation reads the block from memory.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (blockIdx.x == 1) {
+      if (t == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      return;
+    }
+    int* ok = reinterpret_cast<int*>(smem);
+    if (t == 0) {
+      int good = 0;
+      for (int spin = 0; spin < (1 << 24); ++spin) {
+        if (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= sync_target) { good = 1; break; }
+        __builtin_amdgcn_s_sleep(8);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      *ok = good;
+      if (!good) P.ws[0].solve_failed = 1;  // never seen: the launch's other workgroups always run
+    }
+    __syncthreads();
+    const int good = *ok;
+    __syncthreads();  // everybody has read the word before the factorisation reuses the LDS
+    if (good) potrf_block<false>(P, Amat, ld, i0, fuse_linv, fuse_linvt, smem, 0, 0);
+    return;
   }
   if (MODE == 1) {
     // L^T goes to the (unused) upper triangle so that the backward substitution reads columns too.  In the
@@ -823,7 +857,7 @@ hipError_t big_solve_cholesky(const DevP& P, const BigWork& W, const int* h_firs
   const int* d_first = h_first ? W.first : nullptr;
   if (!P.dense_S)  // otherwise the elimination has written the blocks where they belong
     hipLaunchKernelGGL(k_unpack_lower, dim3((ncam * 36 + 255) / 256, ncam), dim3(256), 0, s, P, W.A, ld);
-  hipLaunchKernelGGL(k_pad_init, dim3((npad + 255) / 256), dim3(256), 0, s, P, W.A, n, npad, ld);
+  hipLaunchKernelGGL(k_pad_init, dim3((npad + 255) / 256), dim3(256), 0, s, P, W.A, n, npad, ld, W.sync);
   // Two-level right-looking factorisation.  Panels of 128 columns are grouped in blocks of kOuter
   // panels.  Inside a block a freshly factored panel only updates the block's remaining panel columns
   // (narrow updates, K = 128); the rest of the trailing matrix is updated once per block with
@@ -837,20 +871,21 @@ hipError_t big_solve_cholesky(const DevP& P, const BigWork& W, const int* h_firs
   static const int outer_override = getenv("HIPBA_CHOL_OUTER") ? atoi(getenv("HIPBA_CHOL_OUTER")) : 0;
   const int kOuter = outer_override > 0 ? outer_override : (nt >= 64 ? 32 : (nt >= 24 ? 16 : 8));
   hipLaunchKernelGGL(k_potrf_inv, dim3(1), dim3(256), kPotrfLds, s, P, W.A, ld, 0, W.Linv, W.LinvT);
+  unsigned sync_arrivals = 0;  // two producers per fused narrow update
   for (int p0 = 0; p0 < nt; p0 += kOuter) {
     const int p1 = p0 + kOuter < nt ? p0 + kOuter : nt;
     for (int p = p0; p < p1; ++p) {
       const int rows = last[p] - p;  // tile rows below the diagonal block that panel p reaches
       hipLaunchKernelGGL(k_gemm_k128<1>, dim3((NB / kTrsmRows) * rows + 1, 1), dim3(256), kLdsTrsm, s, P, W.A, ld, p + 1, 0,
                          p * NB, (const double*)(W.Linv + (long long)p * NB * NB), (double*)nullptr, (double*)nullptr,
-                         (NB / kTrsmRows) * rows + 1, nt * NB);
+                         (NB / kTrsmRows) * rows + 1, nt * NB, (unsigned*)nullptr, 0u);
       if (p + 1 < p1) {  // bring the block's remaining panel columns up to date with panel p (K = 128); factor p + 1
         // grid.x padded to a multiple of 8: workgroups go to the 8 XCDs round-robin by linear index, so with
         // that width an XCD keeps the same row tiles for every column tile and finds their panel rows in its L2
         const int cols = (p1 - 1 < last[p] ? p1 - 1 : last[p]) - p;
         hipLaunchKernelGGL(k_gemm_k128<0>, dim3((2 * rows + 1 + 7) / 8 * 8, 2 * cols), dim3(256),
                            kLdsK128Fused, s, P, W.A, ld, p + 1, p + 1, p * NB, (const double*)nullptr, W.Linv, W.LinvT,
-                           2 * rows + 1, nt * NB);
+                           2 * rows + 1, nt * NB, W.sync, (sync_arrivals += 2));
       }
     }
     if (p1 < nt) {  // trailing update with the whole block (K = kOuter * 128) inside its envelope; factor panel p1

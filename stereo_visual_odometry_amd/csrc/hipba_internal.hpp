@@ -45,6 +45,7 @@ struct BigWork {
   double* pcg = nullptr;   // PCG vectors and scalars
   double* Minv = nullptr;  // [36 * ncam] block-Jacobi preconditioner
   int* first = nullptr;    // [npad/NB + 1] first tile column of every tile row of the factor's envelope
+  unsigned* sync = nullptr;  // arrival counter of the in-launch hand-offs of one factorisation
   size_t bytes() const;
 };
 constexpr int kCholNB = 128;
