@@ -43,6 +43,7 @@ size_t big_work_bytes(int n, int ncam) {
   b += rup((size_t)36 * ncam * 8, 256);      // Minv
   b += rup((npad / NB + 1) * sizeof(int), 256);  // first
   b += 256;                                      // sync
+  b += rup((npad / NB) * (npad / NB + 1) / 2 * sizeof(int2), 256);  // tiles
   return b + 1024;
 }
 
@@ -57,7 +58,8 @@ void big_work_bind(BigWork& W, int n, int ncam, void* base) {
   W.pcg = reinterpret_cast<double*>(p); p += rup((6 * npad + kPcgScalars + 3 * (size_t)ncam + 64) * 8, 256);
   W.Minv = reinterpret_cast<double*>(p); p += rup((size_t)36 * ncam * 8, 256);
   W.first = reinterpret_cast<int*>(p); p += rup((npad / NB + 1) * sizeof(int), 256);
-  W.sync = reinterpret_cast<unsigned*>(p);
+  W.sync = reinterpret_cast<unsigned*>(p); p += 256;
+  W.tiles = reinterpret_cast<int2*>(p);
 }
 
 // ---- packed blocks -> dense column-major lower ----------------------------------------------------
@@ -85,6 +87,26 @@ __global__ __launch_bounds__(256) void k_zero_lower(DevP P, double* A, int n, in
 }
 hipError_t big_zero_lower(const DevP& P, const BigWork& W, hipStream_t s) {
   hipLaunchKernelGGL(k_zero_lower, dim3(W.n), dim3(256), 0, s, P, W.A, W.n, W.ld);
+  return hipGetLastError();
+}
+
+// Sharded solves exchange the reduced matrix as the 128x128 tiles inside its envelope, packed one after another
+// (to_buf: matrix -> buffer before the all-reduce; otherwise buffer -> matrix after it).  One workgroup per tile.
+__global__ __launch_bounds__(256) void k_env_tiles(DevP P, double* A, int ld, const int2* tiles, double* buf, int to_buf) {
+  if (!P.ws[0].active) return;
+  const int2 tl = tiles[blockIdx.x];  // (tile row, tile column)
+  double* a = A + (long long)tl.y * NB * ld + (long long)tl.x * NB;
+  double* b = buf + (long long)blockIdx.x * NB * NB;
+  const int r = (threadIdx.x & 63) * 2;
+  for (int c = threadIdx.x >> 6; c < NB; c += 4) {
+    double2* pa = reinterpret_cast<double2*>(a + (long long)c * ld + r);
+    double2* pb = reinterpret_cast<double2*>(b + c * NB + r);
+    if (to_buf) *pb = *pa; else *pa = *pb;
+  }
+}
+hipError_t big_env_tiles(const DevP& P, const BigWork& W, int n_tiles, double* buf, int to_buf, hipStream_t s) {
+  if (n_tiles <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_env_tiles, dim3(n_tiles), dim3(256), 0, s, P, W.A, W.ld, (const int2*)W.tiles, buf, to_buf);
   return hipGetLastError();
 }
 

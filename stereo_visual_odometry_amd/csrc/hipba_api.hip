@@ -1056,9 +1056,7 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
   const int schur_parts = schur_parts_for(P.n_windows, R->max_pm_blocks);
   // gathered elimination (one writer per block of the reduced matrix) + the dense factorisation: the blocks go
   // straight into the factorisation's matrix, no packed copy
-  const bool direct = P.n_chunks > 0 && !sharded && !small && solver == HIPBA_LINEAR_DENSE_CHOLESKY;
-  P.dense_S = direct ? R->big.A : nullptr;
-  P.dense_ld = direct ? R->big.ld : 0;
+  bool direct = P.n_chunks > 0 && !small && solver == HIPBA_LINEAR_DENSE_CHOLESKY;
 
   auto allreduce = [&](double* buf, size_t n, int op) -> int {
     if (!sharded) return 0;
@@ -1084,6 +1082,33 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
     for (size_t i = 0; i < nt1; ++i) R->env_first[i] = (int)(-neg[i]);
     HIPBA_HIP(hipMemcpyAsync(R->big.first, R->env_first.data(), sizeof(int) * nt1, hipMemcpyHostToDevice, s));
   }
+  // Sharded + gathered elimination + dense factorisation: every rank writes its blocks straight into the dense
+  // matrix and the ranks exchange only the 128x128 tiles inside the (merged) envelope, packed into the buffer of the
+  // packed reduced matrix.  All ranks must take the same path: they agree on it (a shard small enough for the
+  // atomic elimination, or an envelope too wide for the buffer, sends everybody down the packed path).
+  int n_env_tiles = 0;
+  if (sharded) {
+    std::vector<int2> tiles;
+    if (direct && env_ready) {
+      const int nt = (int)R->env_first.size() - 1;
+      for (int i = 0; i < nt; ++i)
+        for (int j = R->env_first[i]; j <= i; ++j) tiles.push_back(make_int2(i, j));
+      if ((long long)tiles.size() * kCholNB * kCholNB > R->S_doubles) tiles.clear();
+    }
+    double agree = tiles.empty() ? 0.0 : -1.0;  // MAX over ranks: 0 as soon as one rank cannot
+    HIPBA_HIP(hipMemcpyAsync(P.wsum, &agree, sizeof(double), hipMemcpyHostToDevice, s));
+    AR(P.wsum, 1, HIPBA_REDUCE_MAX);
+    HIPBA_HIP(hipMemcpyAsync(&agree, P.wsum, sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPBA_HIP(hipStreamSynchronize(s));
+    direct = agree < 0.0;
+    if (direct) {
+      n_env_tiles = (int)tiles.size();
+      HIPBA_HIP(hipMemcpyAsync(R->big.tiles, tiles.data(), sizeof(int2) * tiles.size(), hipMemcpyHostToDevice, s));
+      HIPBA_HIP(hipStreamSynchronize(s));  // `tiles` goes out of scope
+    }
+  }
+  P.dense_S = direct ? R->big.A : nullptr;
+  P.dense_ld = direct ? R->big.ld : 0;
 
   // iteration 0: cost at the starting point, fixed cost, Jacobi scaling
   HIPBA_HIP(launch_cost(P, lm, 0, n_act_blk, 0, 1, false, s));
@@ -1134,7 +1159,7 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
     PHASE(0);
     // S is zeroed first so that, unsharded, the camera-block launch can initialise the reduced system too
     if (direct) {
-      if (!R->S_fully_written) HIPBA_HIP(big_zero_lower(P, R->big, s));
+      if (!R->S_fully_written || sharded) HIPBA_HIP(big_zero_lower(P, R->big, s));
     } else if (R->S_doubles && !(R->S_fully_written && !sharded) && !(control_zeroes_S && iter > 1)) {
       HIPBA_HIP(hipMemsetAsync(P.S, 0, sizeof(double) * (size_t)R->S_doubles, s));
     }
@@ -1147,7 +1172,11 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
     if (!fuse_init) HIPBA_HIP(launch_init_reduced(P, lm, owner, s));
     HIPBA_HIP(launch_point_schur(P, lm, small_ncam, schur_parts, s));
     if (sharded) {
-      if (R->S_doubles) AR(P.S, (size_t)R->S_doubles, HIPBA_REDUCE_SUM);
+      if (direct) {
+        HIPBA_HIP(big_env_tiles(P, R->big, n_env_tiles, P.S, 1, s));
+        AR(P.S, (size_t)n_env_tiles * kCholNB * kCholNB, HIPBA_REDUCE_SUM);
+        HIPBA_HIP(big_env_tiles(P, R->big, n_env_tiles, P.S, 0, s));
+      } else if (R->S_doubles) AR(P.S, (size_t)R->S_doubles, HIPBA_REDUCE_SUM);
       if (P.n_act_poses) AR(P.b, 6 * (size_t)P.n_act_poses, HIPBA_REDUCE_SUM);
       HIPBA_HIP(launch_window_gradient(P, lm, kReduce, s));
       AR(P.wsum, 1, HIPBA_REDUCE_MAX);

@@ -46,6 +46,7 @@ struct BigWork {
   double* Minv = nullptr;  // [36 * ncam] block-Jacobi preconditioner
   int* first = nullptr;    // [npad/NB + 1] first tile column of every tile row of the factor's envelope
   unsigned* sync = nullptr;  // arrival counter of the in-launch hand-offs of one factorisation
+  int2* tiles = nullptr;     // (tile row, tile column) of the lower-triangle tiles inside the envelope (sharded solves)
   size_t bytes() const;
 };
 constexpr int kCholNB = 128;
@@ -56,6 +57,8 @@ void big_work_bind(BigWork& W, int n, int ncam, void* base);
 hipError_t big_solve_cholesky(const DevP& P, const BigWork& W, const int* h_first, hipStream_t s);
 // zeroes the lower triangle of W.A: for solves whose elimination writes the blocks of S straight into it (DevP::dense_S)
 hipError_t big_zero_lower(const DevP& P, const BigWork& W, hipStream_t s);
+// copies the tiles listed in W.tiles between the dense matrix and a packed buffer (sharded solves' exchange)
+hipError_t big_env_tiles(const DevP& P, const BigWork& W, int n_tiles, double* buf, int to_buf, hipStream_t s);
 // block-Jacobi preconditioned conjugate gradients on the packed S
 hipError_t big_solve_pcg(const DevP& P, const BigWork& W, int max_iter, double tol, hipStream_t s);
 

@@ -210,7 +210,8 @@ __device__ __forceinline__ void init_reduced_pose(const DevP& P, const LmParams&
         v += dg * inv_radius;
       }
       if (P.dense_S) {
-        if (j >= i) P.dense_S[(long long)(6 * slot + i) * P.dense_ld + 6 * slot + j] = v;  // lower triangle only
+        // lower triangle only; in a sharded solve one rank contributes U + D^2 (the matrix was zeroed before)
+        if (j >= i && owner) P.dense_S[(long long)(6 * slot + i) * P.dense_ld + 6 * slot + j] = v;
       } else if (owner) {
         Sb[6 * i + j] = v;  // sharded solves: one rank contributes U + D^2 and g_c
       }
