@@ -9,6 +9,8 @@ from stereo_visual_odometry_amd import hipba, scenes
 from stereo_visual_odometry_amd.sharded import ShardedProblem, TorchComm
 
 def main():
+    import faulthandler
+    faulthandler.dump_traceback_later(120, exit=True)  # a mismatch between the ranks' collectives shows as a hang
     rank = int(os.environ["RANK"])
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     torch.cuda.set_device(0)

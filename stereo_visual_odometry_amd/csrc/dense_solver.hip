@@ -577,6 +577,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if ((int)blockIdx.x >= row_tiles) return;  // padding of the grid width
   // FUSE: the three 64x64 tiles of the diagonal block (i0, i0) are updated like any other tile, by workgroups
   // (0,0), (1,0) and (1,1); the last two then signal, and (0,0) waits for them and factors the block.
+  // (sync == null: the factorising workgroup does the whole update of its block itself, no hand-off)
+  if (MODE == 0 && fuse_linv && !sync && blockIdx.x < 2 && blockIdx.y < 2) {
+    if (blockIdx.x == 0 && blockIdx.y == 0 && P.ws[0].active && !P.ws[0].solve_failed)
+      potrf_block<true>(P, Amat, ld, i0, fuse_linv, fuse_linvt, smem, kcol, NB);
+    return;
+  }
   const bool diag_part = MODE == 0 && fuse_linv && blockIdx.x < 2 && blockIdx.y < 2;
   // the row chunks of the panel's envelope, then one chunk of the right-hand side's tile row
   const int row0 = (int)blockIdx.x == row_tiles - 1 ? rhs_row0 : i0 * NB + blockIdx.x * TI;

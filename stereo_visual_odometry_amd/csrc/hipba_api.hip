@@ -1071,40 +1071,38 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
   // of its own landmarks only: the ranks merge their envelopes (element-wise minimum of the first tile columns)
   // before the first factorisation.
   bool env_ready = R->has_big && !R->env_first.empty();
+  // Sharded + gathered elimination + dense factorisation: every rank writes its blocks straight into the dense
+  // matrix and the ranks exchange only the 128x128 tiles inside the (merged) envelope, packed into the buffer of the
+  // packed reduced matrix.  All ranks must take the same path, so whether every rank can rides along in the
+  // envelope's all-reduce as one more word (a shard small enough for the atomic elimination, or an envelope too
+  // wide for the buffer, sends everybody down the packed path).
+  int n_env_tiles = 0;
+  if (sharded) direct = direct && env_ready;
   if (env_ready && sharded) {
     const size_t nt1 = R->env_first.size();
-    std::vector<double> neg(nt1);
+    std::vector<double> neg(nt1 + 1);
     for (size_t i = 0; i < nt1; ++i) neg[i] = -(double)R->env_first[i];
-    HIPBA_HIP(hipMemcpyAsync(P.yc, neg.data(), sizeof(double) * nt1, hipMemcpyHostToDevice, s));
-    AR(P.yc, nt1, HIPBA_REDUCE_MAX);
-    HIPBA_HIP(hipMemcpyAsync(neg.data(), P.yc, sizeof(double) * nt1, hipMemcpyDeviceToHost, s));
+    neg[nt1] = direct ? -1.0 : 0.0;  // MAX over ranks: 0 as soon as one rank cannot
+    HIPBA_HIP(hipMemcpyAsync(P.yc, neg.data(), sizeof(double) * (nt1 + 1), hipMemcpyHostToDevice, s));
+    AR(P.yc, nt1 + 1, HIPBA_REDUCE_MAX);
+    HIPBA_HIP(hipMemcpyAsync(neg.data(), P.yc, sizeof(double) * (nt1 + 1), hipMemcpyDeviceToHost, s));
     HIPBA_HIP(hipStreamSynchronize(s));
     for (size_t i = 0; i < nt1; ++i) R->env_first[i] = (int)(-neg[i]);
     HIPBA_HIP(hipMemcpyAsync(R->big.first, R->env_first.data(), sizeof(int) * nt1, hipMemcpyHostToDevice, s));
-  }
-  // Sharded + gathered elimination + dense factorisation: every rank writes its blocks straight into the dense
-  // matrix and the ranks exchange only the 128x128 tiles inside the (merged) envelope, packed into the buffer of the
-  // packed reduced matrix.  All ranks must take the same path: they agree on it (a shard small enough for the
-  // atomic elimination, or an envelope too wide for the buffer, sends everybody down the packed path).
-  int n_env_tiles = 0;
-  if (sharded) {
-    std::vector<int2> tiles;
-    if (direct && env_ready) {
-      const int nt = (int)R->env_first.size() - 1;
+    direct = neg[nt1] < 0.0;
+    if (direct) {
+      std::vector<int2> tiles;
+      const int nt = (int)nt1 - 1;
       for (int i = 0; i < nt; ++i)
         for (int j = R->env_first[i]; j <= i; ++j) tiles.push_back(make_int2(i, j));
-      if ((long long)tiles.size() * kCholNB * kCholNB > R->S_doubles) tiles.clear();
-    }
-    double agree = tiles.empty() ? 0.0 : -1.0;  // MAX over ranks: 0 as soon as one rank cannot
-    HIPBA_HIP(hipMemcpyAsync(P.wsum, &agree, sizeof(double), hipMemcpyHostToDevice, s));
-    AR(P.wsum, 1, HIPBA_REDUCE_MAX);
-    HIPBA_HIP(hipMemcpyAsync(&agree, P.wsum, sizeof(double), hipMemcpyDeviceToHost, s));
-    HIPBA_HIP(hipStreamSynchronize(s));
-    direct = agree < 0.0;
-    if (direct) {
-      n_env_tiles = (int)tiles.size();
-      HIPBA_HIP(hipMemcpyAsync(R->big.tiles, tiles.data(), sizeof(int2) * tiles.size(), hipMemcpyHostToDevice, s));
-      HIPBA_HIP(hipStreamSynchronize(s));  // `tiles` goes out of scope
+      // (the merged envelope is the same on every rank, and so is this test)
+      if ((long long)tiles.size() * kCholNB * kCholNB > R->S_doubles) {
+        direct = false;
+      } else {
+        n_env_tiles = (int)tiles.size();
+        HIPBA_HIP(hipMemcpyAsync(R->big.tiles, tiles.data(), sizeof(int2) * tiles.size(), hipMemcpyHostToDevice, s));
+        HIPBA_HIP(hipStreamSynchronize(s));  // `tiles` goes out of scope
+      }
     }
   }
   P.dense_S = direct ? R->big.A : nullptr;

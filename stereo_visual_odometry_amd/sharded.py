@@ -8,6 +8,7 @@ of the landmarks with all of their observations, so landmark elimination is rank
 reduced camera matrix, its right-hand side and a handful of scalars are summed.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -52,6 +53,8 @@ class TorchComm:
 
     def _allreduce(self, ctx, buf, count, op, stream):
         try:
+            if os.environ.get("HIPBA_TRACE_COMM"):
+                print("rank %d all-reduce #%d count %d op %d" % (self.rank, self.calls, count, op), flush=True)
             t = tensor_from_pointer(buf, count, self.device)
             rop = dist.ReduceOp.SUM if op == hipba.REDUCE_SUM else dist.ReduceOp.MAX
             if self.device.type == "cuda":
