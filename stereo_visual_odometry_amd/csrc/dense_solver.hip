@@ -44,6 +44,7 @@ size_t big_work_bytes(int n, int ncam) {
   b += rup((npad / NB + 1) * sizeof(int), 256);  // first
   b += 256;                                      // sync
   b += rup((npad / NB) * (npad / NB + 1) / 2 * sizeof(int2), 256);  // tiles
+  b += rup((npad / NB + 1) * sizeof(unsigned), 256);                // flags
   return b + 1024;
 }
 
@@ -59,7 +60,8 @@ void big_work_bind(BigWork& W, int n, int ncam, void* base) {
   W.Minv = reinterpret_cast<double*>(p); p += rup((size_t)36 * ncam * 8, 256);
   W.first = reinterpret_cast<int*>(p); p += rup((npad / NB + 1) * sizeof(int), 256);
   W.sync = reinterpret_cast<unsigned*>(p); p += 256;
-  W.tiles = reinterpret_cast<int2*>(p);
+  W.tiles = reinterpret_cast<int2*>(p); p += rup((npad / NB) * (npad / NB + 1) / 2 * sizeof(int2), 256);
+  W.flags = reinterpret_cast<unsigned*>(p);
 }
 
 // ---- packed blocks -> dense column-major lower ----------------------------------------------------
@@ -113,10 +115,11 @@ hipError_t big_env_tiles(const DevP& P, const BigWork& W, int n_tiles, double* b
 // rows beyond n: identity on the padded diagonal, and b^T as row npad -- the first row of one extra tile row.
 // Factorising [S; b^T] row-wise like any other row block leaves z^T = (L^-1 b)^T in that row: the forward
 // substitution costs no launches of its own.
-__global__ void k_pad_init(DevP P, double* A, int n, int npad, int ld, unsigned* sync) {
+__global__ void k_pad_init(DevP P, double* A, int n, int npad, int ld, unsigned* sync, unsigned* flags) {
   if (!P.ws[0].active) return;
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
   if (col == 0) *sync = 0u;  // arrivals of the diagonal-block hand-offs of this factorisation (k_gemm_k128)
+  if (col <= npad / NB) flags[col] = 0u;  // "y_k is ready" words of the backward sweep (k_trsv_pipeline)
   if (col >= npad) return;
   for (int row = n; row < ld; ++row) A[(long long)col * ld + row] = (row == col) ? 1.0 : 0.0;
   if (col < n) A[(long long)col * ld + npad] = P.b[6ll * P.wd[0].cam_base + col];
@@ -837,6 +840,97 @@ __global__ __launch_bounds__(kTrsvThreads) void k_trsv_bwd(DevP P, const double*
   if (t < NB) y[(k - 1) * NB + t] = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
 }
 
+// The whole backward sweep in ONE launch: workgroup j (dispatched in the order the sweep needs them, last row
+// block first) owns row block j.  It applies z_j -= L(k,j)^T y_k for the row blocks k below it inside the envelope,
+// last one first, each as soon as y_k has been published, then forms y_j = Linv_j^T z_j and publishes it.  The
+// tile of the next step is already in registers while the workgroup waits, so a link of the chain is one flag
+// hand-off, a 1 KB read and two 128x128 matrix-vector products instead of a launch.
+// Hand-off without fences: y and the flags are written with write-through (agent-scope atomic) stores by one
+// workgroup, drained, then the flag is raised by one lane behind the workgroup's barrier; readers poll the flag and
+// read y with agent-scope loads only, behind a barrier of their own.  Every workgroup is resident at once (the
+// host uses this kernel for at most one workgroup per CU), and a workgroup only ever waits for lower-indexed ones.
+__global__ __launch_bounds__(kTrsvThreads) void k_trsv_pipeline(DevP P, const double* A, int ld, int nt, int npad,
+                                                                const int* first, const double* LinvT_all, double* y,
+                                                                unsigned* flags) {
+  __shared__ double zj[NB];
+  __shared__ double yk[NB];
+  __shared__ double part[4][NB];
+  __shared__ int s_last, s_ok;
+  if (!P.ws[0].active || P.ws[0].solve_failed) return;  // the same answer in every workgroup: nobody is left waiting
+  const int t = threadIdx.x, r = t & (NB - 1), h = t >> 7;
+  const int j = nt - 1 - (int)blockIdx.x;
+  if (t == 0) { s_last = j; s_ok = 1; }
+  __syncthreads();
+  // last row block below j whose envelope reaches back to column block j
+  if (t < nt && t > j && (!first || first[t] <= j)) atomicMax(&s_last, t);
+  if (t < NB) zj[t] = A[(long long)(j * NB + t) * ld + npad];  // z_j: the right-hand side's row of the factored matrix
+  const double* Li = LinvT_all + (long long)j * NB * NB;
+  // two register buffers: the tile in use and the one on its way; the inverse block Linv_j takes the second one's
+  // place in the last step (and is all there is for the bottom block)
+  double u[32], un[32];
+#define TRSV_LINV_LOAD(dst) \
+  { _Pragma("unroll") for (int i = 0; i < 32; ++i) dst[i] = Li[(h * 32 + i) * NB + r]; }
+  __syncthreads();
+  const int klast = s_last;
+#define TRSV_TILE_LOAD(dst, k_)                                                                   \
+  {                                                                                               \
+    const double* U_ = A + (long long)(k_) * NB * ld + (long long)j * NB;                         \
+    _Pragma("unroll") for (int i = 0; i < 32; ++i) dst[i] = U_[(long long)(h * 32 + i) * ld + r]; \
+  }
+  if (klast > j) TRSV_TILE_LOAD(u, klast) else TRSV_LINV_LOAD(u);
+  for (int k = klast; k > j; --k) {
+    if (k - 1 > j) TRSV_TILE_LOAD(un, k - 1) else TRSV_LINV_LOAD(un);  // on its way while this step waits and computes
+    if (t == 0) {
+      int ok = 0;
+      for (int spin = 0; spin < (1 << 22); ++spin) {
+        if (__hip_atomic_load(flags + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 1; break; }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      if (!ok) s_ok = 0;
+    }
+    __syncthreads();
+    if (!s_ok) break;
+    if (t < NB) yk[t] = __hip_atomic_load(y + k * NB + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    {
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int i = 0; i < 32; i += 2) {
+        s0 += u[i] * yk[h * 32 + i];
+        s1 += u[i + 1] * yk[h * 32 + i + 1];
+      }
+      part[h][r] = s0 + s1;
+    }
+    __syncthreads();
+    if (t < NB) zj[t] -= (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) u[i] = un[i];
+  }
+#undef TRSV_TILE_LOAD
+#undef TRSV_LINV_LOAD
+  __syncthreads();
+  if (!s_ok) {  // never seen: a producer of this launch did not arrive
+    if (t == 0) P.ws[0].solve_failed = 1;
+    return;
+  }
+  {
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 32; i += 2) {
+      s0 += u[i] * zj[h * 32 + i];  // (u holds Linv_j^T by now)
+      s1 += u[i + 1] * zj[h * 32 + i + 1];
+    }
+    part[h][r] = s0 + s1;
+  }
+  __syncthreads();
+  if (t < NB)
+    __hip_atomic_store(y + j * NB + t, (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (t == 0) __hip_atomic_store(flags + j, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __global__ void k_store_solution(DevP P, const double* y, int n) {
   if (!P.ws[0].active || P.ws[0].solve_failed) return;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -885,7 +979,7 @@ hipError_t big_solve_cholesky(const DevP& P, const BigWork& W, const int* h_firs
   const int* d_first = h_first ? W.first : nullptr;
   if (!P.dense_S)  // otherwise the elimination has written the blocks where they belong
     hipLaunchKernelGGL(k_unpack_lower, dim3((ncam * 36 + 255) / 256, ncam), dim3(256), 0, s, P, W.A, ld);
-  hipLaunchKernelGGL(k_pad_init, dim3((npad + 255) / 256), dim3(256), 0, s, P, W.A, n, npad, ld, W.sync);
+  hipLaunchKernelGGL(k_pad_init, dim3((npad + 255) / 256), dim3(256), 0, s, P, W.A, n, npad, ld, W.sync, W.flags);
   // Two-level right-looking factorisation.  Panels of 128 columns are grouped in blocks of kOuter
   // panels.  Inside a block a freshly factored panel only updates the block's remaining panel columns
   // (narrow updates, K = 128); the rest of the trailing matrix is updated once per block with
@@ -923,13 +1017,24 @@ hipError_t big_solve_cholesky(const DevP& P, const BigWork& W, const int* h_firs
     }
   }
   double* z = W.rhs + npad;
-  hipLaunchKernelGGL(k_extract_z, dim3((npad + 255) / 256), dim3(256), 0, s, P, (const double*)W.A, npad, ld, z);
   double* y = W.rhs;
-  hipLaunchKernelGGL(k_trsv_first, dim3(1), dim3(kTrsvThreads), 0, s, P, nt - 1, (const double*)W.LinvT, (const double*)z, y);
-  for (int k = nt - 1; k >= 1; --k) {
-    const int j0 = first[k] < k ? first[k] : k - 1;
-    hipLaunchKernelGGL(k_trsv_bwd, dim3(k - j0), dim3(kTrsvThreads), 0, s, P, (const double*)W.A, ld, k, j0,
-                       (const double*)W.LinvT, z, y);
+  static const int max_resident = [] {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 0;
+  }();
+  if (nt <= max_resident) {
+    // the sweep as one launch of nt workgroups that hand y_k to each other (at most one per CU: all resident)
+    hipLaunchKernelGGL(k_trsv_pipeline, dim3(nt), dim3(kTrsvThreads), 0, s, P, (const double*)W.A, ld, nt, npad, d_first,
+                       (const double*)W.LinvT, y, W.flags);
+  } else {
+    hipLaunchKernelGGL(k_extract_z, dim3((npad + 255) / 256), dim3(256), 0, s, P, (const double*)W.A, npad, ld, z);
+    hipLaunchKernelGGL(k_trsv_first, dim3(1), dim3(kTrsvThreads), 0, s, P, nt - 1, (const double*)W.LinvT, (const double*)z, y);
+    for (int k = nt - 1; k >= 1; --k) {
+      const int j0 = first[k] < k ? first[k] : k - 1;
+      hipLaunchKernelGGL(k_trsv_bwd, dim3(k - j0), dim3(kTrsvThreads), 0, s, P, (const double*)W.A, ld, k, j0,
+                         (const double*)W.LinvT, z, y);
+    }
   }
   hipLaunchKernelGGL(k_store_solution, dim3((n + 255) / 256), dim3(256), 0, s, P, y, n);
   return hipGetLastError();

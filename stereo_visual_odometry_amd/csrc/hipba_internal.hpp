@@ -46,6 +46,7 @@ struct BigWork {
   double* Minv = nullptr;  // [36 * ncam] block-Jacobi preconditioner
   int* first = nullptr;    // [npad/NB + 1] first tile column of every tile row of the factor's envelope
   unsigned* sync = nullptr;  // arrival counter of the in-launch hand-offs of one factorisation
+  unsigned* flags = nullptr; // [npad/NB + 1] "y_k is ready" words of the backward sweep
   int2* tiles = nullptr;     // (tile row, tile column) of the lower-triangle tiles inside the envelope (sharded solves)
   size_t bytes() const;
 };
