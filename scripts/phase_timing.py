@@ -19,14 +19,19 @@ def main():
     dp = solver.upload(probs)
     if which == "potrf":
         ms = dp.time_kernel(hipba.KERNEL_REDUCED_SOLVE, 1)
-        n = 8
+        n = 4096
         buf = (C.c_ulonglong * (8 * n))()
         lib.hipba_debug_ticks.argtypes = [C.c_void_p, C.c_int]
         lib.hipba_debug_ticks(buf, 8 * n)
-        t = np.frombuffer(buf, dtype=np.uint64).astype(np.int64)[:8]
-        print("reduced_solve %.2f ms; last panel factorisation in shader cycles: load %d, 8 tile steps %d, store %d, inverse %d" % (
-            ms, t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3]))
-        print("tile step 2: panel %d, trailing update beside the next diagonal tile %d" % (t[6] - t[5], t[7] - t[6]))
+        t = np.frombuffer(buf, dtype=np.uint64).astype(np.int64).reshape(n, 8)
+        print("reduced_solve %.2f ms" % ms)
+        for k in (2, 20, 40, 60, 92):
+            f, u, st, wk = t[k], t[2048 + k], t[1024 + k], t[3072 + k]
+            print("block %2d (shader cycles): factoring workgroup waits %d, load %d, 8 tile steps %d, store %d, inverse %d" % (
+                k, u[1] - u[0], f[1] - f[0], f[2] - f[1], f[3] - f[2], f[4] - f[3]))
+            print("   strip 0: solve %d, publish %d, block rows %d, waits for all strips %d, band update %d; strip 3: block rows %d" % (
+                st[1] - st[0], st[2] - st[1], st[3] - st[2], st[4] - st[3], st[7] - st[4], st[6] - st[5]))
+            print("   first plain worker: waits for the strips %d, band update %d" % (wk[1] - wk[0], wk[2] - wk[1]))
         return
     ms = dp.time_kernel(hipba.KERNEL_POINT_SCHUR, 5)
     print("point_schur %.1f us" % (1e3 * ms))

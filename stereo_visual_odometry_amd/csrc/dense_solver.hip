@@ -44,7 +44,7 @@ size_t big_work_bytes(int n, int ncam) {
   b += rup((npad / NB + 1) * sizeof(int), 256);  // first
   b += 256;                                      // sync
   b += rup((npad / NB) * (npad / NB + 1) / 2 * sizeof(int2), 256);  // tiles
-  b += rup((npad / NB + 1) * sizeof(unsigned), 256);                // flags
+  b += rup(2 * (npad / NB + 1) * sizeof(unsigned), 256);            // flags, tile counters
   return b + 1024;
 }
 
@@ -118,8 +118,9 @@ hipError_t big_env_tiles(const DevP& P, const BigWork& W, int n_tiles, double* b
 __global__ void k_pad_init(DevP P, double* A, int n, int npad, int ld, unsigned* sync, unsigned* flags) {
   if (!P.ws[0].active) return;
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col == 0) *sync = 0u;  // arrivals of the diagonal-block hand-offs of this factorisation (k_gemm_k128)
-  if (col <= npad / NB) flags[col] = 0u;  // "y_k is ready" words of the backward sweep (k_trsv_pipeline)
+  if (col < 3) sync[col] = 0u;  // hand-off words of this factorisation's launches (see k_update_stream)
+  // "y_k is ready" words of the backward sweep (k_trsv_pipeline), then the tile counters of the band updates
+  if (col < 2 * (npad / NB + 1)) flags[col] = 0u;
   if (col >= npad) return;
   for (int row = n; row < ld; ++row) A[(long long)col * ld + row] = (row == col) ? 1.0 : 0.0;
   if (col < n) A[(long long)col * ld + npad] = P.b[6ll * P.wd[0].cam_base + col];
@@ -198,7 +199,7 @@ __device__ __forceinline__ void potrf_block(const DevP& P, double* A, int ld, in
   int& fail = *reinterpret_cast<int*>(smem + (NTL * (NTL + 1) / 2) * kTile);
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   double* Akk = A + (long long)k * NB * ld + (long long)k * NB;
-  HIPBA_CYCLES(0);
+  HIPBA_CYCLES_AT(k, 0);
   if (UPD) {
     // wave w owns tile rows w and 7 - w of the lower triangle: nine tiles, accumulated (negated, transposed:
     // register r of lane l is element (l & 15, (l >> 4) + 4 r)) over all stages.  The products are bound by the
@@ -251,7 +252,7 @@ __device__ __forceinline__ void potrf_block(const DevP& P, double* A, int ld, in
   }
   if (t == 0) fail = 0;
   __syncthreads();
-  HIPBA_CYCLES(1);
+  HIPBA_CYCLES_AT(k, 1);
 
   // (a) Cholesky of the 16x16 diagonal tile jd by one wave, in registers: lane r < 16 holds row r, the pivots and
   // multipliers travel between lanes as wave-uniform scalars (v_readlane).  The tile's inverse comes out of the same
@@ -297,7 +298,7 @@ __device__ __forceinline__ void potrf_block(const DevP& P, double* A, int ld, in
   if (wave == 0) diag_tile(0);
   __syncthreads();
   for (int j = 0; j < NTL; ++j) {
-    if (j == 2) HIPBA_CYCLES(5);
+    if (j == 2) HIPBA_CYCLES_AT(k, 5);
     if (fail) break;
     // (b) panel below the diagonal tile: L(i,j) = A(i,j) L(j,j)^-T, one matrix-core tile product each with the
     // tile's inverse (the result replaces the tile: every lane has read its operands before the first store)
@@ -311,7 +312,7 @@ __device__ __forceinline__ void potrf_block(const DevP& P, double* A, int ld, in
       }
     }
     __syncthreads();
-    if (j == 2) HIPBA_CYCLES(6);
+    if (j == 2) HIPBA_CYCLES_AT(k, 6);
     // (c) trailing tiles: A(i2,j2) -= L(i2,j) L(j2,j)^T, again held transposed in the accumulator.  Wave 0 takes
     // the next diagonal tile alone and factors it at once (the longest single-wave job of a step) while the
     // other three waves share the remaining tiles.
@@ -339,9 +340,9 @@ __device__ __forceinline__ void potrf_block(const DevP& P, double* A, int ld, in
       }
     }
     __syncthreads();
-    if (j == 2) HIPBA_CYCLES(7);
+    if (j == 2) HIPBA_CYCLES_AT(k, 7);
   }
-  HIPBA_CYCLES(2);
+  HIPBA_CYCLES_AT(k, 2);
   if (fail) {
     if (t == 0) P.ws[0].solve_failed = 1;
     return;
@@ -355,7 +356,7 @@ __device__ __forceinline__ void potrf_block(const DevP& P, double* A, int ld, in
       for (int bj = 0; bj < bi; ++bj) Akk[(long long)(TB * bj + q) * ld + TB * bi + pr] = Lt[ltile(bi, bj) + t];
   }
   __syncthreads();
-  HIPBA_CYCLES(3);
+  HIPBA_CYCLES_AT(k, 3);
   // (d) X = L^-1 by tile columns; wave w takes columns w and 7 - w.  The tiles of the current column stay in
   // registers: an accumulator tile D(p, q) sits in exactly the lanes and registers the B operand of the next
   // product wants (k = p, n = q), so X(tt, j) feeds y += L(i, tt) X(tt, j) and Y feeds X(i, j) = -Dinv(i) Y
@@ -404,7 +405,7 @@ __device__ __forceinline__ void potrf_block(const DevP& P, double* A, int ld, in
       }
     }
   }
-  HIPBA_CYCLES(4);
+  HIPBA_CYCLES_AT(k, 4);
 }
 
 __global__ __launch_bounds__(256) void k_potrf_inv(DevP P, double* A, int ld, int k, double* Linv_all,
@@ -414,43 +415,40 @@ __global__ __launch_bounds__(256) void k_potrf_inv(DevP P, double* A, int ld, in
   potrf_block<false>(P, A, ld, k, Linv_all, LinvT_all, smem, 0, 0);
 }
 
-// ---- fp64 matrix-core GEMM, C(i,j) (op)= sum_k A(i,k) B(j,k), column-major, 128x128 tiles ----------
-// MODE 0: update        A(i,j) -= sum over panel columns [kcol, kcol + K) of L(i,k) L(j,k)
-//                       (1-D grid over the tiles (i0 + r, j0 + c), c <= r < m, plus row m in full)
-// MODE 1: panel solve   L(i,k)   = A(i,k) Linv(k)^T    (in place: the workgroup owns the tile; K = 128)
+// ---- fp64 matrix-core GEMM, C(i,j) -= sum_k A(i,k) B(j,k), column-major, 128x128 tiles ----------------
+// Trailing update A(i,j) -= sum over panel columns [kcol, kcol + K) of L(i,k) L(j,k): a 1-D grid over the tiles
+// (i0 + r, j0 + c), c <= r < m, plus row m in full.
 //
 // The product is computed transposed (D[p][q] = C(i0+q, j0+p)) so that the 16 lanes sharing an
 // accumulator register hold 16 consecutive rows of one column: stores are 128-byte runs.
 constexpr int KC = 16;            // k-depth of one LDS stage
 constexpr int LDT = 128 + 16;     // LDS row pitch (doubles): the two k-groups of a half-wave land 32 banks apart
 
-// FUSE (MODE 0, fuse_linv != null): workgroup 0, which owns the diagonal tile (i0, j0), brings that tile up to
+// FUSE (fuse_linv != null): workgroup 0, which owns the diagonal tile (i0, j0), brings that tile up to
 // date itself and goes on to factor it (potrf_block): the next panel factorisation, one workgroup's work on the
 // critical path, runs beside this launch's other tiles instead of after them.
 constexpr size_t kGemmNtLds = (size_t)4 * KC * LDT * 8;
-// ENVELOPE (MODE 0): first[i] is the first tile column of tile row i that can be non-zero (monotone in i): of the
+// ENVELOPE: first[i] is the first tile column of tile row i that can be non-zero (monotone in i): of the
 // panel columns [kcol, kcol + K) a tile in row i needs only those from first[i] * NB on -- the factor is zero before
 // them.  Tile row m of the grid is the right-hand side (tile row rhs_tile of the matrix), which is dense.
-template <int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm_nt(DevP P, double* Amat, int ld, int i0, int j0, int kcol, int K,
-                                                 const double* Linv, long long Linv_or_m, double* fuse_linv,
-                                                 double* fuse_linvt, const int* first, int rhs_tile) {
+                                                 int m, double* fuse_linv, double* fuse_linvt, const int* first,
+                                                 int rhs_tile) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double (*sA)[KC * LDT] = reinterpret_cast<double (*)[KC * LDT]>(smem);                 // i-tile, two stages
   double (*sB)[KC * LDT] = reinterpret_cast<double (*)[KC * LDT]>(smem + 2 * KC * LDT);  // j-tile
   if (!P.ws[0].active || P.ws[0].solve_failed) return;
-  if (MODE == 0 && fuse_linv && blockIdx.x == 0) {
+  if (fuse_linv && blockIdx.x == 0) {
     const int skip = first ? max(0, first[i0] * NB - kcol) : 0;
     potrf_block<true>(P, Amat, ld, i0, fuse_linv, fuse_linvt, smem, kcol + skip, K - skip);
     return;
   }
   int ti, tj;
-  if (MODE == 0) {
+  {
     // One workgroup per tile of the lower triangle of an m x m tile grid (row by row), then one per tile of an
     // extra full row m (the right-hand side): a 1-D grid without idle workgroups.  Workgroups go to the eight
     // XCDs round-robin by index, so every XCD gets the same number of tiles whatever m is (a 2-D grid with
     // early exits above the diagonal left some XCDs up to 17 % more tiles than others for odd widths).
-    const int m = (int)Linv_or_m;
     const int id = blockIdx.x, tri = m * (m + 1) / 2;
     int r, c;
     if (id < tri) {
@@ -467,20 +465,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       if (skip > 0) { kcol += skip; K -= skip; }
       if (K <= 0) return;
     }
-  } else {
-    ti = i0 + blockIdx.x; tj = j0 + blockIdx.y;
   }
   const double* Ap = Amat + (long long)kcol * ld + (long long)ti * NB;   // rows of tile i, panel columns
-  const double* Bp;
-  int ldb;
-  double* Cp;
-  if (MODE == 0) {
-    Bp = Amat + (long long)kcol * ld + (long long)tj * NB; ldb = ld;
-    Cp = Amat + (long long)tj * NB * ld + (long long)ti * NB;
-  } else {
-    Bp = Linv; ldb = NB;
-    Cp = Amat + (long long)kcol * ld + (long long)ti * NB;
-  }
+  const double* Bp = Amat + (long long)kcol * ld + (long long)tj * NB;   // rows of tile j
+  const int ldb = ld;
+  double* Cp = Amat + (long long)tj * NB * ld + (long long)ti * NB;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wr = wave >> 1, wc = wave & 1;  // wave's 64x64 quadrant: rows (i) wr, cols (j) wc
   const int lcol = t >> 4, lrow = (t & 15) * 8;  // staging: column of the chunk, first of 8 rows
@@ -541,120 +530,73 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int r = 0; r < 4; ++r) {
         const int col = wc * 64 + a * 16 + (lane >> 4) + 4 * r;
         const int row = wr * 64 + b * 16 + (lane & 15);
-        double* dst = Cp + (long long)col * ld + row;
-        if (MODE == 0) {
-          *dst -= acc[a][b][r];
-        } else {
-          *dst = acc[a][b][r];
-          // L^T goes to the (unused) upper triangle so that the backward substitution reads columns too
-          Amat[(long long)(ti * NB + row) * ld + kcol + col] = acc[a][b][r];
-        }
+        Cp[(long long)col * ld + row] -= acc[a][b][r];
       }
     }
   }
 }
 
 // ---- the K = 128 steps of the panel chain ------------------------------------------------------------------
-// Same products as k_gemm_nt, for one panel (K = NB) and 64-row tiles:
-//   MODE 0: A(i,j) -= L(i,k) L(j,k)^T on 64x64 tiles,   MODE 1: L(i,k) = A(i,k) Linv(k)^T on 32x128 tiles.
-// These launches are short (a few hundred tiles, 4 MFLOP each) and sit on the critical path between two panel
-// factorisations; with one LDS stage in flight they were bound by eight back-to-back load latencies.  Here the
-// k-loop is fully unrolled and DEPTH stages of global loads are in flight at any time (all eight for the
-// 64x64 update, whose destination tile is fetched up front as well).
-// FUSE (MODE 0, fuse_linv != null, launched with i0 == j0): workgroup (0, 0) updates the whole diagonal block
-// (i0, i0) itself and factors it (potrf_block); its three 64x64 tiles are skipped by the others.
-constexpr int kTrsmRows = 32;  // rows per workgroup of the panel solve: 32 -> twice the workgroups of 64, all stages in flight
-template <int MODE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm_k128(DevP P, double* Amat, int ld, int i0, int j0, int kcol,
-                                                     const double* Linv, double* fuse_linv, double* fuse_linvt,
-                                                     int row_tiles, int rhs_row0, unsigned* sync, unsigned sync_target) {
-  constexpr int TI = MODE == 0 ? 64 : kTrsmRows, TJ = MODE == 0 ? 64 : NB;
+// Panel solve L(i,k) = A(i,k) Linv(k)^T, in place, one workgroup per 32 rows of the panel's envelope (the last one
+// takes the right-hand side's row).  The launch is short (a hundred-odd strips, 0.5 MFLOP each) and sits on the
+// critical path between two panel factorisations; with one LDS stage in flight it was bound by eight back-to-back
+// load latencies, so the k-loop is fully unrolled and all eight stages of global loads are in flight from the start.
+// The inverse is lower triangular: the 16 columns of sub-tile ct only need the stages c <= ct; the waves take the
+// sub-tiles {0, 3, 4, 7} and {1, 2, 5, 6}, 18 stage products each instead of 32.
+constexpr int kTrsmRows = 32;  // rows per workgroup: 32 -> twice the workgroups of 64, all stages in flight
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_panel_solve(
+    DevP P, double* Amat, int ld, int i0, int kcol, const double* Linv, int strips, int rhs_row0) {
+  constexpr int TI = kTrsmRows, TJ = NB;
   constexpr int LDA = TI + 16, LDB = TJ + 16;
   constexpr int PA = TI / 16, PB = TJ / 16;    // doubles per thread and stage
-  constexpr int MI = TI / 32, MJ = TJ / 32;    // 16x16 sub-tiles per wave
-  constexpr int NCH = NB / KC;                 // 8 stages
-  constexpr int DEPTH = (MODE == 0 || TI <= 32) ? 8 : 4;  // stages of global loads in flight (register budget)
+  constexpr int MJ = TJ / 32;                  // 16x16 sub-tiles per wave (one row of them)
+  constexpr int NCH = NB / KC;                 // 8 stages, all in flight
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double (*sA)[KC * LDA] = reinterpret_cast<double (*)[KC * LDA]>(smem);
   double (*sB)[KC * LDB] = reinterpret_cast<double (*)[KC * LDB]>(smem + 2 * KC * LDA);
-  if ((int)blockIdx.x >= row_tiles) return;  // padding of the grid width
-  // FUSE: the three 64x64 tiles of the diagonal block (i0, i0) are updated like any other tile, by workgroups
-  // (0,0), (1,0) and (1,1); the last two then signal, and (0,0) waits for them and factors the block.
-  // (sync == null: the factorising workgroup does the whole update of its block itself, no hand-off)
-  if (MODE == 0 && fuse_linv && !sync && blockIdx.x < 2 && blockIdx.y < 2) {
-    if (blockIdx.x == 0 && blockIdx.y == 0 && P.ws[0].active && !P.ws[0].solve_failed)
-      potrf_block<true>(P, Amat, ld, i0, fuse_linv, fuse_linvt, smem, kcol, NB);
-    return;
-  }
-  const bool diag_part = MODE == 0 && fuse_linv && blockIdx.x < 2 && blockIdx.y < 2;
-  // the row chunks of the panel's envelope, then one chunk of the right-hand side's tile row
-  const int row0 = (int)blockIdx.x == row_tiles - 1 ? rhs_row0 : i0 * NB + blockIdx.x * TI;
-  const int col0 = MODE == 0 ? j0 * NB + blockIdx.y * TJ : 0;
-  if (MODE == 0 && col0 > row0 + TI - 1) return;  // wholly above the diagonal
+  // the row strips of the panel's envelope, then the strip of the right-hand side's tile row
+  const int row0 = (int)blockIdx.x == strips - 1 ? rhs_row0 : i0 * NB + blockIdx.x * TI;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  // Column sub-tile a of this wave starts at column K128_CT(a).  MODE 0: the wave's half of the tile.  MODE 1: the
-  // inverse is lower triangular, so the 16 columns of sub-tile ct only need the stages c <= ct; the waves take the
-  // sub-tiles {0, 3, 4, 7} and {1, 2, 5, 6}, 18 stage products each instead of 32.
 #define K128_CTILE(a) (2 * (a) + (((a) ^ wc) & 1))
-#define K128_CT(a) (MODE == 0 ? wc * (TJ / 2) + (a) * 16 : K128_CTILE(a) * 16)
   const int lcol = t >> 4, lsub = t & 15;
   const double* Ap = Amat + (long long)kcol * ld + row0;
-  const double* Bp = MODE == 0 ? Amat + (long long)kcol * ld + col0 : Linv;
-  const int ldb = MODE == 0 ? ld : NB;
-  double* Cp = MODE == 0 ? Amat + (long long)col0 * ld + row0 : Amat + (long long)kcol * ld + row0;
+  double* Cp = Amat + (long long)kcol * ld + row0;
 
-  v2d ra[DEPTH][PA / 2], rb[DEPTH][PB / 2];
-#define K128_GLOAD(slot, chunk)                                                                                   \
+  v2d ra[NCH][PA / 2], rb[NCH][PB / 2];
+#define K128_GLOAD(chunk)                                                                                         \
   {                                                                                                               \
-    const v2d* a_ = reinterpret_cast<const v2d*>(Ap + (long long)((chunk)*KC + lcol) * ld + lsub * PA);   \
-    const v2d* b_ = reinterpret_cast<const v2d*>(Bp + (long long)((chunk)*KC + lcol) * ldb + lsub * PB);  \
-    _Pragma("unroll") for (int m = 0; m < PA / 2; ++m) ra[slot][m] = a_[m];                                       \
-    _Pragma("unroll") for (int m = 0; m < PB / 2; ++m) rb[slot][m] = b_[m];                                       \
+    const v2d* a_ = reinterpret_cast<const v2d*>(Ap + (long long)((chunk)*KC + lcol) * ld + lsub * PA);           \
+    const v2d* b_ = reinterpret_cast<const v2d*>(Linv + (long long)((chunk)*KC + lcol) * NB + lsub * PB);         \
+    _Pragma("unroll") for (int m = 0; m < PA / 2; ++m) ra[chunk][m] = a_[m];                                      \
+    _Pragma("unroll") for (int m = 0; m < PB / 2; ++m) rb[chunk][m] = b_[m];                                      \
   }
   // (stage indices are written out as literals: with a loop counter the staging registers ended up in scratch)
-  K128_GLOAD(0, 0); K128_GLOAD(1, 1); K128_GLOAD(2, 2); K128_GLOAD(3, 3);
-  if constexpr (DEPTH == 8) { K128_GLOAD(4, 4); K128_GLOAD(5, 5); K128_GLOAD(6, 6); K128_GLOAD(7, 7); }
-  // destination tile (MODE 0): fetched now, used after the last stage
-  double cold[MJ][MI][4];
-  if (MODE == 0) {
-#pragma unroll
-    for (int a = 0; a < MJ; ++a)
-#pragma unroll
-      for (int b = 0; b < MI; ++b)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          cold[a][b][r] = Cp[(long long)(K128_CT(a) + (lane >> 4) + 4 * r) * ld + wr * (TI / 2) + b * 16 + (lane & 15)];
-  }
+  K128_GLOAD(0) K128_GLOAD(1) K128_GLOAD(2) K128_GLOAD(3) K128_GLOAD(4) K128_GLOAD(5) K128_GLOAD(6) K128_GLOAD(7)
   const bool live = P.ws[0].active && !P.ws[0].solve_failed;  // uniform; tested after the loads are on their way
 
-  v4d acc[MJ][MI];
+  v4d acc[MJ];
 #pragma unroll
-  for (int a = 0; a < MJ; ++a)
-#pragma unroll
-    for (int b = 0; b < MI; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+  for (int a = 0; a < MJ; ++a) acc[a] = (v4d){0.0, 0.0, 0.0, 0.0};
   if (!live) return;
 
 #define K128_STAGE(c)                                                                                             \
   {                                                                                                               \
-    constexpr int buf = (c) & 1, slot = (c) % DEPTH;                                                              \
+    constexpr int buf = (c) & 1;                                                                                  \
     {                                                                                                             \
-      v2d* a_ = reinterpret_cast<v2d*>(&sA[buf][lcol * LDA + lsub * PA]);                                 \
-      v2d* b_ = reinterpret_cast<v2d*>(&sB[buf][lcol * LDB + lsub * PB]);                                 \
-      _Pragma("unroll") for (int m = 0; m < PA / 2; ++m) a_[m] = ra[slot][m];                                     \
-      _Pragma("unroll") for (int m = 0; m < PB / 2; ++m) b_[m] = rb[slot][m];                                     \
+      v2d* a_ = reinterpret_cast<v2d*>(&sA[buf][lcol * LDA + lsub * PA]);                                         \
+      v2d* b_ = reinterpret_cast<v2d*>(&sB[buf][lcol * LDB + lsub * PB]);                                         \
+      _Pragma("unroll") for (int m = 0; m < PA / 2; ++m) a_[m] = ra[c][m];                                        \
+      _Pragma("unroll") for (int m = 0; m < PB / 2; ++m) b_[m] = rb[c][m];                                        \
     }                                                                                                             \
     __syncthreads(); /* stage c visible; everybody is past the reads of stage c - 2, which shared this buffer */  \
-    if constexpr ((c) + DEPTH < NCH) K128_GLOAD(slot, (c) + DEPTH);                                               \
     _Pragma("unroll") for (int kk = 0; kk < KC / 4; ++kk) {                                                       \
       const int kr = kk * 4 + (lane >> 4);                                                                        \
-      double fb[MI];                                                                                              \
-      _Pragma("unroll") for (int m = 0; m < MI; ++m) fb[m] = sA[buf][kr * LDA + (lane & 15) + wr * (TI / 2) + m * 16]; \
+      const double fb = sA[buf][kr * LDA + (lane & 15) + wr * (TI / 2)];                                          \
       _Pragma("unroll") for (int a = 0; a < MJ; ++a) {                                                            \
-        if (MODE == 0 || (c) <= K128_CTILE(a)) {                                                                  \
-          const double fa = sB[buf][kr * LDB + (lane & 15) + K128_CT(a)];                                         \
-          _Pragma("unroll") for (int b = 0; b < MI; ++b)                                                          \
-              acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, fb[b], acc[a][b], 0, 0, 0);                    \
+        if ((c) <= K128_CTILE(a)) {                                                                               \
+          const double fa = sB[buf][kr * LDB + (lane & 15) + 16 * K128_CTILE(a)];                                 \
+          acc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, fb, acc[a], 0, 0, 0);                                 \
         }                                                                                                         \
       }                                                                                                           \
     }                                                                                                             \
@@ -664,86 +606,235 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #undef K128_STAGE
 #undef K128_GLOAD
 #pragma unroll
-  for (int a = 0; a < MJ; ++a) {
+  for (int a = 0; a < MJ; ++a)
 #pragma unroll
-    for (int b = 0; b < MI; ++b) {
+    for (int r = 0; r < 4; ++r)
+      Cp[(long long)(16 * K128_CTILE(a) + (lane >> 4) + 4 * r) * ld + wr * (TI / 2) + (lane & 15)] = acc[a][r];
+  // L^T goes to the (unused) upper triangle so that the backward substitution reads columns too.  In the
+  // accumulators consecutive lanes hold consecutive ROWS of L; each wave turns its RW x 64 block around in LDS,
+  // 32 columns at a time, so that consecutive lanes write consecutive columns (256-byte runs, not 8-byte ones).
+  constexpr int TP = 33;                      // staging pitch (doubles): odd, no bank conflicts on the way back
+  constexpr int RW = TI / 2;                  // rows of a wave's block
+  __syncthreads();                            // every wave is done reading the last stage
+  double* stg = &sB[0][0] + wave * RW * TP;   // 4 x 4.2 KB inside sB
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int col = K128_CT(a) + (lane >> 4) + 4 * r;
-        const int row = wr * (TI / 2) + b * 16 + (lane & 15);
-        double* dst = Cp + (long long)col * ld + row;
-        if (MODE == 0) *dst = cold[a][b][r] - acc[a][b][r];
-        else *dst = acc[a][b][r];
-      }
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) stg[(lane & 15) * TP + a2 * 16 + (lane >> 4) + 4 * r] = acc[2 * half + a2][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // RW rows x 32 columns: lanes 0-31 take the columns of row rr, lanes 32-63 those of row rr + 1
+#pragma unroll
+    for (int rr = 0; rr < RW; rr += 2) {
+      const int rl = rr + (lane >> 5), cl = lane & 31;
+      Amat[(long long)(row0 + wr * RW + rl) * ld + kcol + 16 * K128_CTILE(2 * half + (cl >> 4)) + (cl & 15)] = stg[rl * TP + cl];
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
-  if (MODE == 0 && diag_part) {
-    // Hand-off of the diagonal block's tiles inside the launch.  Producers: every storing wave drains its stores,
-    // the workgroup meets, one lane releases at agent scope and counts itself in.  Consumer (0,0): drains its own
-    // stores, one lane polls the counter (bounded), acquires at agent scope (which also drops this CU's L1 lines of
-    // the block), the workgroup meets, and the factorisation reads the block from memory.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef K128_CTILE
+}
+
+// ---- the K = 128 update of a whole band, streamed ---------------------------------------------------------------
+// A(i,j) -= L(i,p) L(j,p)^T on the 64x64 tiles of the row strips [0, row_strips) x column strips [0, col_strips)
+// below panel p that lie on or below the diagonal (the last row strip is the right-hand side's), numbered column by
+// column.  One launch of at most as many workgroups as the chip holds at two per CU; workgroup b takes tiles b,
+// b + (grid - 1), ... and keeps its loads running across the tile boundary: four stages of operands are always in
+// flight, those of the next tile are issued while the last stages of this one are multiplied, and the destination
+// tile is fetched half a tile ahead of its read-modify-write.
+// Workgroup 0 takes tile 0 -- tile (0,0) of the next diagonal block -- waits for the block's other two tiles (numbers
+// 1 and row_strips; hand-off through sync[0]) and factors the block (potrf_block): the next panel factorisation, one
+// workgroup's work on the critical path, runs beside this launch's other tiles.  It runs 1.5x slower when another
+// workgroup multiplies on the same CU (8 tile steps: 87k cycles instead of 59k), so workgroup 0 posts where it runs
+// (sync[1]) and a workgroup that finds itself on that CU posts its index (sync[2]) and leaves at once; whoever
+// finishes its own tiles first -- the tiles rarely divide evenly -- draws the leaver's from a counter.  (Drawing
+// every tile from a counter was tried: a returning atomic among the loads makes the compiler wait for all of them,
+// once per tile.)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_update_stream(
+    DevP P, double* Amat, int ld, int i0, int kcol, double* fuse_linv, double* fuse_linvt, int row_strips,
+    int col_strips, int rhs_row0, unsigned* orphan_draw, unsigned* sync, unsigned sync_target) {
+  constexpr int TS = 64, LDS_ = TS + 16, PT = TS / 16, NCH = NB / KC;
+  static_assert(NCH == 8 && PT == 4, "the stages are written out");
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double (*sA)[KC * LDS_] = reinterpret_cast<double (*)[KC * LDS_]>(smem);
+  double (*sB)[KC * LDS_] = reinterpret_cast<double (*)[KC * LDS_]>(smem + 2 * KC * LDS_);
+  int* nxt = reinterpret_cast<int*>(smem + 4 * KC * LDS_);
+  if (!P.ws[0].active || P.ws[0].solve_failed) return;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int lcol = t >> 5, lsub = (t & 31) * 2;  // staging: column (and column + 8) of a stage, first of two rows
+  const int total = col_strips * row_strips - col_strips * (col_strips - 1) / 2;
+  const bool factoring = blockIdx.x == 0;
+  // the CU this workgroup runs on, tagged with the launch (the words are not reset between launches)
+  const unsigned tag = sync_target << 12;
+  const unsigned here = tag | (__smid() & 0xfffu);
+  const int stride = (int)gridDim.x - 1;
+  int n = blockIdx.x;
+  // sync[2], the leaver's word: tag | kPosted | index once a workgroup has left, | kPassed once a workgroup has gone
+  // past the point where it looks for a leaver's tiles.  A workgroup may only leave while nobody has passed (one
+  // compare-and-swap decides), so whoever passes afterwards -- everybody else -- sees the posting.
+  constexpr unsigned kPosted = 1u << 10, kPassed = 1u << 11;
+  if (factoring) {
+    if (t == 0) {
+      __hip_atomic_store(sync + 2, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(sync + 1, here, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  } else {
+    if (t == 0) {
+      unsigned leave = 0;
+      // (relaxed on purpose: an acquire here would have every workgroup of the launch invalidate its L2; if sync[2]'s
+      // initial value is not visible yet the swap fails and the workgroup simply stays)
+      if (__hip_atomic_load(sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == here) {
+        unsigned expect = tag;
+        leave = __hip_atomic_compare_exchange_strong(sync + 2, &expect, tag | kPosted | blockIdx.x, __ATOMIC_RELAXED,
+                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      nxt[0] = (int)leave;
+    }
     __syncthreads();
-    if (blockIdx.x == 1) {
+    const bool leave = nxt[0] != 0;
+    __syncthreads();  // everybody has read the word before it is written again
+    if (leave) return;
+  }
+  if (n >= total) return;
+  const double* pan = Amat + (long long)kcol * ld;
+#define STREAM_DECODE(n_, row0_, col0_)                                     \
+  {                                                                         \
+    int y_ = 0, len_ = row_strips, m_ = (n_);                               \
+    while (m_ >= len_) { m_ -= len_; --len_; ++y_; }                        \
+    const int x_ = y_ + m_;                                                 \
+    row0_ = x_ == row_strips - 1 ? rhs_row0 : i0 * NB + x_ * TS;            \
+    col0_ = i0 * NB + y_ * TS;                                              \
+  }
+  int row0, col0, row0n = 0, col0n = 0;
+  STREAM_DECODE(n, row0, col0);
+  v2d ra[4][PT / 2], rb[4][PT / 2];
+  // staging: half-wave h of the workgroup (8 of them) takes columns h and h + 8 of a 16-column stage, lane l of the
+  // half-wave rows 2l and 2l + 1: every load instruction of a wave reads two whole 512-byte columns
+#define STREAM_GLOAD(slot, chunk, r0_, c0_)                                                                    \
+  {                                                                                                            \
+    _Pragma("unroll") for (int m = 0; m < PT / 2; ++m) {                                                       \
+      const long long o_ = (long long)((chunk)*KC + 8 * m + lcol) * ld + lsub;                                 \
+      ra[slot][m] = *reinterpret_cast<const v2d*>(pan + o_ + (r0_));                                           \
+      rb[slot][m] = *reinterpret_cast<const v2d*>(pan + o_ + (c0_));                                           \
+    }                                                                                                          \
+  }
+  STREAM_GLOAD(0, 0, row0, col0); STREAM_GLOAD(1, 1, row0, col0); STREAM_GLOAD(2, 2, row0, col0); STREAM_GLOAD(3, 3, row0, col0);
+  bool own = true;  // still on its own tiles (then: on a leaver's)
+  for (;;) {
+    const int n_next = n + stride;
+    const bool has_next = own && !factoring && n_next < total;
+    if (has_next) STREAM_DECODE(n_next, row0n, col0n);
+    v4d acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+    double cold[2][2][4];
+    double* Cp = Amat + (long long)col0 * ld + row0;
+    // (stage indices are literals: with a loop counter the staging registers ended up in scratch)
+#define STREAM_STAGE(c, AFTER_SYNC)                                                                  \
+  {                                                                                                               \
+    constexpr int buf = (c) & 1, slot = (c) & 3;                                                                  \
+    {                                                                                                             \
+      _Pragma("unroll") for (int m = 0; m < PT / 2; ++m) {                                                        \
+        *reinterpret_cast<v2d*>(&sA[buf][(8 * m + lcol) * LDS_ + lsub]) = ra[slot][m];                            \
+        *reinterpret_cast<v2d*>(&sB[buf][(8 * m + lcol) * LDS_ + lsub]) = rb[slot][m];                            \
+      }                                                                                                           \
+    }                                                                                                             \
+    __syncthreads(); /* stage c visible; everybody is past the reads of the stage before last (same buffer) */    \
+    AFTER_SYNC                                                                                                    \
+    _Pragma("unroll") for (int kk = 0; kk < KC / 4; ++kk) {                                                       \
+      const int kr = kk * 4 + (lane >> 4);                                                                        \
+      double fb[2];                                                                                               \
+      _Pragma("unroll") for (int m = 0; m < 2; ++m) fb[m] = sA[buf][kr * LDS_ + (lane & 15) + wr * 32 + m * 16];  \
+      _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                                             \
+        const double fa = sB[buf][kr * LDS_ + (lane & 15) + wc * 32 + a * 16];                                    \
+        _Pragma("unroll") for (int b = 0; b < 2; ++b)                                                             \
+            acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, fb[b], acc[a][b], 0, 0, 0);                      \
+      }                                                                                                           \
+    }                                                                                                             \
+  }
+    STREAM_STAGE(0, STREAM_GLOAD(0, 4, row0, col0);)
+    STREAM_STAGE(1, STREAM_GLOAD(1, 5, row0, col0);)
+    STREAM_STAGE(2, STREAM_GLOAD(2, 6, row0, col0);)
+    STREAM_STAGE(3, STREAM_GLOAD(3, 7, row0, col0);
+                 _Pragma("unroll") for (int a = 0; a < 2; ++a) _Pragma("unroll") for (int b = 0; b < 2; ++b)
+                 _Pragma("unroll") for (int r = 0; r < 4; ++r)
+                     cold[a][b][r] = Cp[(long long)(wc * 32 + a * 16 + (lane >> 4) + 4 * r) * ld + wr * 32 + b * 16 + (lane & 15)];)
+    STREAM_STAGE(4, if (has_next) STREAM_GLOAD(0, 0, row0n, col0n);)
+    STREAM_STAGE(5, if (has_next) STREAM_GLOAD(1, 1, row0n, col0n);)
+    STREAM_STAGE(6, if (has_next) STREAM_GLOAD(2, 2, row0n, col0n);)
+    STREAM_STAGE(7, if (has_next) STREAM_GLOAD(3, 3, row0n, col0n);)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          Cp[(long long)(wc * 32 + a * 16 + (lane >> 4) + 4 * r) * ld + wr * 32 + b * 16 + (lane & 15)] = cold[a][b][r] - acc[a][b][r];
+    // Hand-off of the diagonal block (i0, i0).  Producers: every storing wave drains its stores, the workgroup
+    // meets, one lane releases at agent scope and counts itself in.
+    if (n == 1 || n == row_strips) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
       if (t == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      return;
     }
-    int* ok = reinterpret_cast<int*>(smem);
+    if (has_next) { n = n_next; row0 = row0n; col0 = col0n; continue; }
+    if (factoring) break;
+    // own tiles done: a leaver's, if there is one (its tiles are leaver, leaver + stride, ...)
+    own = false;
+    __syncthreads();  // the last stage's reads are over: the word below shares nothing with them, but keep it simple
     if (t == 0) {
-      int good = 0;
-      for (int spin = 0; spin < (1 << 24); ++spin) {
-        if (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= sync_target) { good = 1; break; }
-        __builtin_amdgcn_s_sleep(8);
+      int take = total;
+      const unsigned o = __hip_atomic_fetch_or(sync + 2, kPassed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((o & ~0xfffu) == tag && (o & kPosted)) {
+        const unsigned k = __hip_atomic_fetch_add(orphan_draw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const long long cand = (long long)(o & (kPosted - 1)) + (long long)k * stride;
+        if (cand < total) take = (int)cand;
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      *ok = good;
-      if (!good) P.ws[0].solve_failed = 1;  // never seen: the launch's other workgroups always run
+      nxt[0] = take;
     }
     __syncthreads();
-    const int good = *ok;
-    __syncthreads();  // everybody has read the word before the factorisation reuses the LDS
-    if (good) potrf_block<false>(P, Amat, ld, i0, fuse_linv, fuse_linvt, smem, 0, 0);
-    return;
+    n = nxt[0];
+    __syncthreads();
+    if (n >= total) break;
+    STREAM_DECODE(n, row0, col0);
+    STREAM_GLOAD(0, 0, row0, col0); STREAM_GLOAD(1, 1, row0, col0); STREAM_GLOAD(2, 2, row0, col0); STREAM_GLOAD(3, 3, row0, col0);
   }
-  if (MODE == 1) {
-    // L^T goes to the (unused) upper triangle so that the backward substitution reads columns too.  In the
-    // accumulators consecutive lanes hold consecutive ROWS of L; each wave turns its RW x 64 block around in LDS,
-    // 32 columns at a time, so that consecutive lanes write consecutive columns (256-byte runs, not 8-byte ones).
-    constexpr int TP = 33;                      // staging pitch (doubles): odd, no bank conflicts on the way back
-    constexpr int RW = TI / 2;                  // rows of a wave's block
-    __syncthreads();                            // every wave is done reading the last stage
-    double* stg = &sB[0][0] + wave * RW * TP;   // at most 4 x 8.4 KB inside sB
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-#pragma unroll
-      for (int a2 = 0; a2 < 2; ++a2) {
-        const int a = 2 * half + a2;
-#pragma unroll
-        for (int b = 0; b < MI; ++b)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            stg[(b * 16 + (lane & 15)) * TP + a2 * 16 + (lane >> 4) + 4 * r] = acc[a][b][r];
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      // RW rows x 32 columns: lanes 0-31 take the columns of row rr, lanes 32-63 those of row rr + 1
-#pragma unroll
-      for (int rr = 0; rr < RW; rr += 2) {
-        const int rl = rr + (lane >> 5), cl = lane & 31;
-        Amat[(long long)(row0 + wr * RW + rl) * ld + kcol + K128_CT(2 * half + (cl >> 4)) + (cl & 15)] = stg[rl * TP + cl];
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+#undef STREAM_STAGE
+#undef STREAM_GLOAD
+#undef STREAM_DECODE
+  if (!factoring) return;
+  HIPBA_CYCLES_AT(2048 + i0, 1);
+  // Consumer: drains its own stores, one lane polls the counter (bounded), acquires at agent scope (which also drops
+  // this CU's L1 lines of the block), the workgroup meets, and the factorisation reads the block from memory.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int* ok = reinterpret_cast<int*>(smem);
+  if (t == 0) {
+    int good = 0;
+    for (int spin = 0; spin < (1 << 24); ++spin) {
+      if (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= sync_target) { good = 1; break; }
+      __builtin_amdgcn_s_sleep(8);
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    *ok = good;
+    if (!good) P.ws[0].solve_failed = 1;  // never seen: the launch's other workgroups always run
   }
-#undef K128_CT
-#undef K128_CTILE
+  __syncthreads();
+  const int good = *ok;
+  HIPBA_CYCLES_AT(2048 + i0, 2);
+  __syncthreads();  // everybody has read the word before the factorisation reuses the LDS
+  if (good) potrf_block<false>(P, Amat, ld, i0, fuse_linv, fuse_linvt, smem, 0, 0);
 }
 
 // ---- backward substitution with the blocked factor (the forward one happens inside the factorisation) ----
@@ -951,13 +1042,13 @@ hipError_t configure_dense_kernels() {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_potrf_inv),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPotrfLds);
   if (e == hipSuccess)
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_k128<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_stream), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)kLdsK128Fused);
   if (e == hipSuccess)
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_k128<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_panel_solve), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)kLdsTrsm);
   if (e == hipSuccess)
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_nt<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_nt), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)kLdsNtFused);
   return e;
 }
@@ -988,41 +1079,83 @@ hipError_t big_solve_cholesky(const DevP& P, const BigWork& W, const int* h_firs
   // there, so only the very first panel factorisation is a launch of its own.  (Overlapping through a second
   // stream was measured and lost 5 %: the panel kernels queue behind 50 us trailing-update workgroups.)
   // Every step covers the tile rows of its panel's envelope plus tile row nt, the right-hand side.
-  // Block size: with the panel factorisations hidden in the narrow updates, wide blocks win -- measured at 94
-  // panels: 8 -> 18.8 ms, 16 -> 17.7, 24 -> 17.7, 32 -> 17.0, 47 -> 19.3 (30 and 34-40: 18.3-19.1).
+  // Block size, dense matrix: with the panel factorisations hidden in the narrow updates, wide blocks win --
+  // measured at 94 panels: 8 -> 18.8 ms, 16 -> 17.7, 24 -> 17.7, 32 -> 17.0, 47 -> 19.3 (30 and 34-40: 18.3-19.1).
+  // With a narrow envelope the picture changes: a narrow update then touches few enough tiles to finish in the
+  // shadow of the panel factorisation it carries, and a wide update -- which hides nothing -- is pure extra time
+  // (band of ~35 tiles, 94 panels: blocks of 32 -> 8.7 ms, 48 -> 8.4, one block -> 7.4).  The block size is picked
+  // per problem from a model of the two launch kinds fitted to traces on MI355X: a narrow launch takes
+  // max(46, 44 + 0.0107 (tiles - 400)) us for its 64x64 tiles on or below the diagonal, a wide one its
+  // multiply-adds at 65 TFLOP/s plus 15 us.
   static const int outer_override = getenv("HIPBA_CHOL_OUTER") ? atoi(getenv("HIPBA_CHOL_OUTER")) : 0;
-  const int kOuter = outer_override > 0 ? outer_override : (nt >= 64 ? 32 : (nt >= 24 ? 16 : 8));
-  hipLaunchKernelGGL(k_potrf_inv, dim3(1), dim3(256), kPotrfLds, s, P, W.A, ld, 0, W.Linv, W.LinvT);
-  unsigned sync_arrivals = 0;  // two producers per fused narrow update
-  for (int p0 = 0; p0 < nt; p0 += kOuter) {
-    const int p1 = p0 + kOuter < nt ? p0 + kOuter : nt;
-    for (int p = p0; p < p1; ++p) {
-      const int rows = last[p] - p;  // tile rows below the diagonal block that panel p reaches
-      hipLaunchKernelGGL(k_gemm_k128<1>, dim3((NB / kTrsmRows) * rows + 1, 1), dim3(256), kLdsTrsm, s, P, W.A, ld, p + 1, 0,
-                         p * NB, (const double*)(W.Linv + (long long)p * NB * NB), (double*)nullptr, (double*)nullptr,
-                         (NB / kTrsmRows) * rows + 1, nt * NB, (unsigned*)nullptr, 0u);
-      if (p + 1 < p1) {  // bring the block's remaining panel columns up to date with panel p (K = 128); factor p + 1
-        // grid.x padded to a multiple of 8: workgroups go to the 8 XCDs round-robin by linear index, so with
-        // that width an XCD keeps the same row tiles for every column tile and finds their panel rows in its L2
-        const int cols = (p1 - 1 < last[p] ? p1 - 1 : last[p]) - p;
-        hipLaunchKernelGGL(k_gemm_k128<0>, dim3((2 * rows + 1 + 7) / 8 * 8, 2 * cols), dim3(256),
-                           kLdsK128Fused, s, P, W.A, ld, p + 1, p + 1, p * NB, (const double*)nullptr, W.Linv, W.LinvT,
-                           2 * rows + 1, nt * NB, W.sync, (sync_arrivals += 2));
+  auto modelled_us = [&](int outer) {
+    double us = 0.0;
+    for (int p0 = 0; p0 < nt; p0 += outer) {
+      const int p1 = p0 + outer < nt ? p0 + outer : nt;
+      for (int p = p0; p + 1 < p1; ++p) {
+        const int rows = last[p] - p, cols = (p1 - 1 < last[p] ? p1 - 1 : last[p]) - p;
+        double tiles = 0.0;
+        for (int y = 0; y < 2 * cols; ++y) tiles += 2 * rows + 1 - y;
+        const double t = 44.0 + 0.0107 * (tiles - 400.0);
+        us += t > 46.0 ? t : 46.0;
+      }
+      if (p1 < nt) {
+        const int m = last[p1 - 1] - p1 + 1;
+        double k_tiles = 0.0;  // 128-deep tile products
+        for (int r = 0; r < m; ++r) {
+          const int kb = first[p1 + r] > p0 ? first[p1 + r] : p0;
+          if (p1 > kb) k_tiles += (double)(p1 - kb) * (r + 1);
+        }
+        k_tiles += (double)(p1 - p0) * m;  // the right-hand side's row
+        us += 15.0 + k_tiles * (2.0 * NB * NB * NB) / 65e6;
       }
     }
-    if (p1 < nt) {  // trailing update with the whole block (K = kOuter * 128) inside its envelope; factor panel p1
-      const int m = last[p1 - 1] - p1 + 1;
-      hipLaunchKernelGGL(k_gemm_nt<0>, dim3(m * (m + 1) / 2 + m), dim3(256), kLdsNtFused, s, P, W.A, ld, p1, p1,
-                         p0 * NB, (p1 - p0) * NB, (const double*)nullptr, (long long)m, W.Linv, W.LinvT, d_first, nt);
+    return us;
+  };
+  int kOuter = outer_override;
+  if (kOuter <= 0) {
+    kOuter = nt >= 64 ? 32 : (nt >= 24 ? 16 : 8);
+    if (h_first) {
+      double best = modelled_us(kOuter);
+      for (int cand : {8, 16, 32, 48, 64, 96, nt}) {
+        if (cand > nt) continue;
+        const double t = modelled_us(cand);
+        if (t < 0.97 * best) { best = t; kOuter = cand; }
+      }
     }
   }
-  double* z = W.rhs + npad;
-  double* y = W.rhs;
   static const int max_resident = [] {
     hipDeviceProp_t prop;
     int dev = 0;
     return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 0;
   }();
+  hipLaunchKernelGGL(k_potrf_inv, dim3(1), dim3(256), kPotrfLds, s, P, W.A, ld, 0, W.Linv, W.LinvT);
+  unsigned sync_arrivals = 0;  // two producers per fused band update
+  const int resident = 2 * (max_resident > 0 ? max_resident : 256);  // two workgroups per CU
+  for (int p0 = 0; p0 < nt; p0 += kOuter) {
+    const int p1 = p0 + kOuter < nt ? p0 + kOuter : nt;
+    for (int p = p0; p < p1; ++p) {
+      const int rows = last[p] - p;  // tile rows below the diagonal block that panel p reaches
+      const int strips = (NB / kTrsmRows) * rows + 1;
+      hipLaunchKernelGGL(k_panel_solve, dim3(strips), dim3(256), kLdsTrsm, s, P, W.A, ld, p + 1, p * NB,
+                         (const double*)(W.Linv + (long long)p * NB * NB), strips, nt * NB);
+      if (p + 1 < p1) {  // bring the block's remaining panel columns up to date with panel p (K = 128); factor p + 1
+        const int cols = (p1 - 1 < last[p] ? p1 - 1 : last[p]) - p;
+        const int row_strips = 2 * rows + 1, col_strips = 2 * cols;
+        const int tiles = col_strips * row_strips - col_strips * (col_strips - 1) / 2;
+        hipLaunchKernelGGL(k_update_stream, dim3(tiles < resident ? tiles : resident), dim3(256), kLdsK128Fused, s, P, W.A,
+                           ld, p + 1, p * NB, W.Linv, W.LinvT, row_strips, col_strips, nt * NB, W.flags + (nt + 1) + p,
+                           W.sync, (sync_arrivals += 2));
+      }
+    }
+    if (p1 < nt) {  // trailing update with the whole block (K = kOuter * 128) inside its envelope; factor panel p1
+      const int m = last[p1 - 1] - p1 + 1;
+      hipLaunchKernelGGL(k_gemm_nt, dim3(m * (m + 1) / 2 + m), dim3(256), kLdsNtFused, s, P, W.A, ld, p1, p1,
+                         p0 * NB, (p1 - p0) * NB, m, W.Linv, W.LinvT, d_first, nt);
+    }
+  }
+  double* z = W.rhs + npad;
+  double* y = W.rhs;
   if (nt <= max_resident) {
     // the sweep as one launch of nt workgroups that hand y_k to each other (at most one per CU: all resident)
     hipLaunchKernelGGL(k_trsv_pipeline, dim3(nt), dim3(kTrsvThreads), 0, s, P, (const double*)W.A, ld, nt, npad, d_first,

@@ -45,8 +45,10 @@ struct BigWork {
   double* pcg = nullptr;   // PCG vectors and scalars
   double* Minv = nullptr;  // [36 * ncam] block-Jacobi preconditioner
   int* first = nullptr;    // [npad/NB + 1] first tile column of every tile row of the factor's envelope
-  unsigned* sync = nullptr;  // arrival counter of the in-launch hand-offs of one factorisation
-  unsigned* flags = nullptr; // [npad/NB + 1] "y_k is ready" words of the backward sweep
+  unsigned* sync = nullptr;  // arrival counter of the in-launch hand-offs of one factorisation; [1]: the CU of the
+                             // workgroup that factors the next diagonal block
+  unsigned* flags = nullptr; // [2 (npad/NB + 1)] "y_k is ready" words of the backward sweep, then one tile counter per
+                             // panel for the streamed band updates
   int2* tiles = nullptr;     // (tile row, tile column) of the lower-triangle tiles inside the envelope (sharded solves)
   size_t bytes() const;
 };
@@ -72,7 +74,10 @@ namespace hipba { extern __device__ unsigned long long g_ticks[8 * 4096]; }
   if (threadIdx.x == 0 && blockIdx.x < 4096) hipba::g_ticks[8 * blockIdx.x + (i)] = wall_clock64()
 #define HIPBA_CYCLES(i) \
   if (threadIdx.x == 0 && blockIdx.x < 4096) hipba::g_ticks[8 * blockIdx.x + (i)] = clock64()
+#define HIPBA_CYCLES_AT(slot, i) \
+  if (threadIdx.x == 0 && (slot) < 4096) hipba::g_ticks[8 * (slot) + (i)] = clock64()
 #else
 #define HIPBA_TICK(i)
 #define HIPBA_CYCLES(i)
+#define HIPBA_CYCLES_AT(slot, i)
 #endif
