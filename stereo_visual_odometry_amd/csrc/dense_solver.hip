@@ -80,15 +80,24 @@ __global__ void k_unpack_lower(DevP P, double* A, int ld) {
 
 // Zeroes the lower triangle of the leading n x n part (one workgroup per column): what a memset of the packed
 // matrix is to the unpacking path when the elimination writes its blocks straight into A but leaves some untouched.
-__global__ __launch_bounds__(256) void k_zero_lower(DevP P, double* A, int n, int ld) {
+// With an envelope (first != null) a column is only zeroed down to the last tile row that reaches it: nothing below
+// is ever written or read.
+__global__ __launch_bounds__(256) void k_zero_lower(DevP P, double* A, int n, int ld, const int* first, int nt) {
   if (!P.ws[0].active) return;
   const int col = blockIdx.x;
+  int end = n;
+  if (first) {
+    int i = nt - 1;
+    while (i > col / NB && first[i] > col / NB) --i;
+    end = min(n, (i + 1) * NB);
+  }
   double* c = A + (long long)col * ld;
   const int r0 = col & ~1;  // 16-byte aligned start: ld is even; the one word above the diagonal is free to zero
-  for (int r = r0 + 2 * threadIdx.x; r < n; r += 512) *reinterpret_cast<double2*>(c + r) = make_double2(0.0, 0.0);
+  for (int r = r0 + 2 * threadIdx.x; r < end; r += 512) *reinterpret_cast<double2*>(c + r) = make_double2(0.0, 0.0);
 }
-hipError_t big_zero_lower(const DevP& P, const BigWork& W, hipStream_t s) {
-  hipLaunchKernelGGL(k_zero_lower, dim3(W.n), dim3(256), 0, s, P, W.A, W.n, W.ld);
+hipError_t big_zero_lower(const DevP& P, const BigWork& W, bool enveloped, hipStream_t s) {
+  hipLaunchKernelGGL(k_zero_lower, dim3(W.n), dim3(256), 0, s, P, W.A, W.n, W.ld, enveloped ? (const int*)W.first : nullptr,
+                     W.npad / NB);
   return hipGetLastError();
 }
 

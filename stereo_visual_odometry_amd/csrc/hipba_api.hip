@@ -1157,7 +1157,7 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
     PHASE(0);
     // S is zeroed first so that, unsharded, the camera-block launch can initialise the reduced system too
     if (direct) {
-      if (!R->S_fully_written || sharded) HIPBA_HIP(big_zero_lower(P, R->big, s));
+      if (!R->S_fully_written || sharded) HIPBA_HIP(big_zero_lower(P, R->big, env_ready, s));
     } else if (R->S_doubles && !(R->S_fully_written && !sharded) && !(control_zeroes_S && iter > 1)) {
       HIPBA_HIP(hipMemsetAsync(P.S, 0, sizeof(double) * (size_t)R->S_doubles, s));
     }
@@ -1780,7 +1780,7 @@ int hipba_time_kernel(hipba_handle h, hipba_device_problem dp, const hipba_optio
       HIPBA_HIP(launch_camera_blocks(P, lm, 0, 0, s));
       HIPBA_HIP(launch_make_scale_c(P, lm.jacobi_scaling, s));
       HIPBA_HIP(launch_point_colnorm(P, lm, s));
-      if (direct) HIPBA_HIP(big_zero_lower(P, dp->big, s));
+      if (direct) HIPBA_HIP(big_zero_lower(P, dp->big, !dp->env_first.empty(), s));
       else if (dp->S_doubles) HIPBA_HIP(hipMemsetAsync(P.S, 0, sizeof(double) * (size_t)dp->S_doubles, s));
       HIPBA_HIP(launch_init_reduced(P, lm, 1, s));
       HIPBA_HIP(launch_point_schur(P, lm, small_ncam, schur_parts, s));
@@ -1830,7 +1830,7 @@ int hipba_time_kernel(hipba_handle h, hipba_device_problem dp, const hipba_optio
       if (kernel == HIPBA_KERNEL_REDUCED_SOLVE) {
         // the factorisation destroys nothing it needs again, but the Schur matrix must be rebuilt per repeat
         for (int i = 0; i < repeats && !rc; ++i) {
-          if (direct) HIPBA_HIP(big_zero_lower(P, dp->big, s));
+          if (direct) HIPBA_HIP(big_zero_lower(P, dp->big, !dp->env_first.empty(), s));
           else if (dp->S_doubles) HIPBA_HIP(hipMemsetAsync(P.S, 0, sizeof(double) * (size_t)dp->S_doubles, s));
           HIPBA_HIP(launch_init_reduced(P, lm, 1, s));
           HIPBA_HIP(launch_point_schur(P, lm, small_ncam, schur_parts, s));

@@ -58,8 +58,9 @@ void big_work_bind(BigWork& W, int n, int ncam, void* base);
 // Cholesky: S (packed, P.S) y = b (P.b) -> P.yc; marks ws.solve_failed when S is not positive definite
 // h_first: the envelope (host copy of W.first, camera_order.hpp), or null for a dense factorisation
 hipError_t big_solve_cholesky(const DevP& P, const BigWork& W, const int* h_first, hipStream_t s);
-// zeroes the lower triangle of W.A: for solves whose elimination writes the blocks of S straight into it (DevP::dense_S)
-hipError_t big_zero_lower(const DevP& P, const BigWork& W, hipStream_t s);
+// zeroes the lower triangle of W.A (enveloped: only inside the envelope in W.first): for solves whose elimination
+// writes the blocks of S straight into it (DevP::dense_S)
+hipError_t big_zero_lower(const DevP& P, const BigWork& W, bool enveloped, hipStream_t s);
 // copies the tiles listed in W.tiles between the dense matrix and a packed buffer (sharded solves' exchange)
 hipError_t big_env_tiles(const DevP& P, const BigWork& W, int n_tiles, double* buf, int to_buf, hipStream_t s);
 // block-Jacobi preconditioned conjugate gradients on the packed S
