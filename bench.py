@@ -100,21 +100,19 @@ def kernel_table(dp, hipba, opts, n_c, n_p, n_o, nnz, flops_solve, single_window
             continue  # the materialising twin is not part of the loop and is timed on one-window problems only
         ms = dp.time_kernel(kid, 5 if name != "reduced_solve" else 2, opts)
         if name == "reduced_solve":
-            # algorithmic flops: what a factorisation has to do inside the envelope of the reduced matrix under the
-            # engine's pose order (the dense figure, which the reference's sparse Cholesky would not pay either, is
-            # listed beside it); batches of small windows: the sum of their dense factorisations
-            # algorithmic flops: the dense factorisation, (6 n_c)^3 / 3 (for a batch of small windows the sum over the
-            # windows).  The engine orders the poses and skips the tiles outside the envelope of the reduced matrix,
-            # so it EXECUTES fewer: that figure and its rate are listed beside the algorithmic one.
+            # algorithmic flops: what a tile-level factorisation has to do inside the envelope of the reduced matrix
+            # under the engine's pose order -- the multiply-adds the kernels execute, counted per 128x128 tile product
+            # (for a batch of small windows: the sum of their dense factorisations).  The dense figure, (6 n_c)^3 / 3,
+            # which the reference's sparse Cholesky would not pay either, is listed beside it as what the same time
+            # would mean for a solver without the envelope.
             dense, env = dp.reduced_solve_flops()
-            flops = dense if flops_solve is None else flops_solve
-            executed = env if flops_solve is None else flops_solve
+            flops = env if flops_solve is None else flops_solve
+            dense = dense if flops_solve is None else flops_solve
             ach = flops / (ms * 1e-3) / 1e12
             rows.append({"kernel": name, "bound": "mfma", "ms": ms, "achieved": ach, "peak": FP64_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS, "traffic": None,
-                         "algorithmic_flops": flops, "executed_flops": executed,
-                         "executed_tflops": executed / (ms * 1e-3) / 1e12,
-                         "executed_frac": executed / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS})
+                         "algorithmic_flops": flops, "dense_flops": dense,
+                         "dense_equivalent_tflops": dense / (ms * 1e-3) / 1e12})
         else:
             ach = algorithmic_bytes(name, n_c, n_p, n_o, nnz) / (ms * 1e-3) / 1e9
             rows.append({"kernel": name, "bound": "hbm", "ms": ms, "achieved": ach, "peak": HBM_PEAK_GBS,
@@ -126,7 +124,7 @@ def roofline_of(rows):
     in_loop = [k for k in rows if k["kernel"] != "residual_jacobian"]
     dom = max(in_loop, key=lambda k: k["ms"])
     out = {k: dom[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
-    for k in ("executed_tflops", "executed_frac"):
+    for k in ("algorithmic_flops", "dense_equivalent_tflops"):
         if k in dom:
             out[k] = dom[k]
     out["kernel"] = dom["kernel"]

@@ -12,8 +12,9 @@ from collections import defaultdict
 SINGLE = {"k_cost": "residual", "k_residual_jacobian": "residual_jacobian", "k_camera_blocks": "camera_blocks",
           "k_backsub": "backsub"}
 GROUPS = {"point_schur": ("k_point_schur", ["k_point_schur", "k_schur_gather", "k_camera_rhs"]),
-          "reduced_solve": ("k_pad_init", ["k_unpack_lower", "k_pad_init", "k_potrf_inv", "k_gemm_k128", "k_gemm_nt", "k_update",
-                                               "k_extract_z", "k_trsv_first", "k_trsv_bwd", "k_store_solution"])}
+          "reduced_solve": ("k_pad_init", ["k_unpack_lower", "k_pad_init", "k_potrf_inv", "k_panel_solve", "k_update_stream",
+                                               "k_gemm_nt", "k_extract_z", "k_trsv_first", "k_trsv_bwd", "k_trsv_pipeline",
+                                               "k_store_solution"])}
 
 def per_kernel(path, counter):
     acc, cnt = defaultdict(float), defaultdict(int)

@@ -1090,12 +1090,12 @@ hipError_t big_solve_cholesky(const DevP& P, const BigWork& W, const int* h_firs
   // Every step covers the tile rows of its panel's envelope plus tile row nt, the right-hand side.
   // Block size, dense matrix: with the panel factorisations hidden in the narrow updates, wide blocks win --
   // measured at 94 panels: 8 -> 18.8 ms, 16 -> 17.7, 24 -> 17.7, 32 -> 17.0, 47 -> 19.3 (30 and 34-40: 18.3-19.1).
-  // With a narrow envelope the picture changes: a narrow update then touches few enough tiles to finish in the
-  // shadow of the panel factorisation it carries, and a wide update -- which hides nothing -- is pure extra time
-  // (band of ~35 tiles, 94 panels: blocks of 32 -> 8.7 ms, 48 -> 8.4, one block -> 7.4).  The block size is picked
-  // per problem from a model of the two launch kinds fitted to traces on MI355X: a narrow launch takes
-  // max(46, 44 + 0.0107 (tiles - 400)) us for its 64x64 tiles on or below the diagonal, a wide one its
-  // multiply-adds at 65 TFLOP/s plus 15 us.
+  // With a narrow envelope the picture changes: a narrow update then touches few enough tiles to finish not long
+  // after the panel factorisation it carries, and a wide update -- which hides nothing -- is pure extra time
+  // (band of ~35 tiles, 94 panels: blocks of 32 -> 8.7 ms, 48 -> 8.4, one block -> 7.4, before the streamed update).
+  // The block size is picked per problem from a model of the two launch kinds fitted to traces on MI355X: a narrow
+  // launch takes max(47, 12 + 0.0198 tiles) us for its 64x64 tiles on or below the diagonal (47 us: the fused
+  // factorisation), a wide one its multiply-adds at 65 TFLOP/s plus 15 us.
   static const int outer_override = getenv("HIPBA_CHOL_OUTER") ? atoi(getenv("HIPBA_CHOL_OUTER")) : 0;
   auto modelled_us = [&](int outer) {
     double us = 0.0;
@@ -1105,8 +1105,8 @@ hipError_t big_solve_cholesky(const DevP& P, const BigWork& W, const int* h_firs
         const int rows = last[p] - p, cols = (p1 - 1 < last[p] ? p1 - 1 : last[p]) - p;
         double tiles = 0.0;
         for (int y = 0; y < 2 * cols; ++y) tiles += 2 * rows + 1 - y;
-        const double t = 44.0 + 0.0107 * (tiles - 400.0);
-        us += t > 46.0 ? t : 46.0;
+        const double t = 12.0 + 0.0198 * tiles;
+        us += t > 47.0 ? t : 47.0;
       }
       if (p1 < nt) {
         const int m = last[p1 - 1] - p1 + 1;
