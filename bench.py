@@ -136,26 +136,39 @@ def oracle_problem(oracle, p):
                           p.point_const)
 
 
-def cpu_baseline(threads):
+def cpu_baseline(threads, solver=None):
     """The CPU oracle (restated Ceres path: numeric central-difference Jacobians, exact solve) on a
-    1/8-scale sample of the workload, same scene generator and starting noise."""
+    1/4-scale sample of the workload, same scene generator and starting noise -- and, for a like-for-like ratio, the
+    engine on that same sample."""
     from oracle import oracle
-    from stereo_visual_odometry_amd import scenes
-    prob, _, _ = scenes.bal_scale_hard(seed=3000, grid=(10, 25), n_points=125_000)
+    from stereo_visual_odometry_amd import hipba, scenes
+    prob, _, _ = scenes.bal_scale_hard(seed=3000, grid=(20, 25), n_points=250_000)
     o = oracle_problem(oracle, prob)
-    iters = 3
+    iters = 4
     opts = oracle.default_options(max_num_iterations=iters, num_threads=threads)
     t0 = time.time()
     s, its = oracle.solve(o, opts)
     dt = time.time() - t0
     done = max(len(its) - 1, 1)
-    return {
+    out = {
         "value": done / dt, "unit": "LM iterations/s", "cores": threads, "kind": "port",
         "sample": "restated-Ceres oracle (numeric central-difference Jacobians, exact Schur+Cholesky solve), "
-                  "%d LM iterations on a 1/8-scale problem from the same generator: 250 cameras x 125k landmarks x "
-                  "1M observations (evaluate %.2fs, linear solve %.2fs); the full-size problem has 8x the observations "
-                  "and a 512x larger factorisation" % (done, s["time_evaluate_s"], s["time_linear_solve_s"]),
+                  "%d LM iterations on a 1/4-scale problem from the same generator and start: 500 cameras x 250k landmarks "
+                  "x 2M observations (evaluate %.2fs, linear solve %.2fs); the full-size problem has 4x the observations "
+                  "and a 64x larger dense factorisation" % (done, s["time_evaluate_s"], s["time_linear_solve_s"]),
     }
+    if solver is not None:
+        dp = solver.upload(prob)
+        go = hipba.default_options(max_num_iterations=iters)
+        dp.solve(go)  # warm-up
+        dp.reset()
+        gs = dp.solve(go)[0]
+        dp.free()
+        # (the two do not end on the same cost: from this start the reference's numeric differentiation and the
+        # engine's closed-form Jacobians already part ways in the first step)
+        out["engine_on_same_sample"] = {"value": max(gs["num_linear_solves"], 1) / gs["time_solve_s"],
+                                        "unit": "LM iterations/s", "lm_iterations": gs["num_linear_solves"]}
+    return out
 
 
 def secondary_measurements(solver, with_cpu, threads):
@@ -446,7 +459,7 @@ def main():
             dp.free()
             result["secondary"] = secondary_measurements(solver, not args.no_cpu_baseline, threads)
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(threads)
+            result["cpu_baseline"] = cpu_baseline(threads, solver)
         print(json.dumps(result))
     if world > 1:
         dist.barrier()
