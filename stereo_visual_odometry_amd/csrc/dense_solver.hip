@@ -385,6 +385,9 @@ __device__ __forceinline__ void potrf_block(const DevP& P, double* A, int ld, in
     }
     v4d xs[NTL];  // X(j + rel, j), rel = 0 .. 7 - j
     xs[0] = tile_load(Lt + ltile(j, j), lane);
+    // the same tile transposed, for the store of L^-1 itself: with the two operands of the last product swapped the
+    // matrix core delivers X^T, whose lanes hold consecutive ROWS of X (128-byte runs instead of 8-byte stores)
+    v4d xt = tile_load_t(Lt + ltile(j, j), lane);
 #pragma unroll
     for (int rel = 0; rel < NTL; ++rel) {
       const int i = j + rel;
@@ -399,16 +402,20 @@ __device__ __forceinline__ void potrf_block(const DevP& P, double* A, int ld, in
               y = __builtin_amdgcn_mfma_f64_16x16x4f64(M[(kk * 4 + (lane >> 4)) * TB + (lane & 15)], xs[rt][kk], y, 0, 0, 0);
           }
           v4d x = (v4d){0.0, 0.0, 0.0, 0.0};
+          xt = (v4d){0.0, 0.0, 0.0, 0.0};
           const double* Di = Lt + ltile(i, i);
 #pragma unroll
-          for (int kk = 0; kk < 4; ++kk)
-            x = __builtin_amdgcn_mfma_f64_16x16x4f64(-Di[(kk * 4 + (lane >> 4)) * TB + (lane & 15)], y[kk], x, 0, 0, 0);
+          for (int kk = 0; kk < 4; ++kk) {
+            const double d = -Di[(kk * 4 + (lane >> 4)) * TB + (lane & 15)];
+            x = __builtin_amdgcn_mfma_f64_16x16x4f64(d, y[kk], x, 0, 0, 0);
+            xt = __builtin_amdgcn_mfma_f64_16x16x4f64(y[kk], d, xt, 0, 0, 0);
+          }
           xs[rel] = x;
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
         {
-          Linv[(long long)(TB * j + (lane & 15)) * NB + TB * i + (lane >> 4) + 4 * r] = xs[rel][r];
+          Linv[(long long)(TB * j + (lane >> 4) + 4 * r) * NB + TB * i + (lane & 15)] = xt[r];
           LinvT[(long long)(TB * i + (lane >> 4) + 4 * r) * NB + TB * j + (lane & 15)] = xs[rel][r];
         }
       }
