@@ -17,12 +17,12 @@
 #include <cstdlib>
 #include <vector>
 
+#include "chol_tiles.hpp"
 #include "hipba_internal.hpp"
 
 namespace hipba {
 
 constexpr int NB = kCholNB;  // 128
-typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));  // (arrays of HIP's double2 class are not promoted to registers)
 
 // ---- workspace -----------------------------------------------------------------------------------
@@ -149,50 +149,7 @@ __global__ void k_extract_z(DevP P, const double* A, int npad, int ld, double* z
 // the trailing tiles are updated on the matrix cores.  L^-1 is then built tile column by tile column
 // (block forward substitution), two tile columns per wave.  The workgroup that factors block k can ride in the
 // launch that updates the rest of the matrix with the previous panel(s): see potrf_block and the FUSE notes below.
-constexpr int TB = 16;
-constexpr int NTL = NB / TB;                      // 8 tile rows
-constexpr int kTile = TB * TB;                    // doubles per tile
-
-__device__ __forceinline__ int ltile(int bi, int bj) { return (bi * (bi + 1) / 2 + bj) * kTile; }
-
-// wave-uniform broadcast of lane `src`'s double (src is a compile-time constant after unrolling)
-__device__ __forceinline__ double bcast_lane(double v, int src) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
-  return __hiloint2double(hi, lo);
-}
-// acc += M * N^T for two column-major 16x16 tiles (negate: acc -= ...)
-template <bool NEG>
-__device__ __forceinline__ v4d mfma_tile(const double* M, const double* N, v4d acc, int lane) {
-#pragma unroll
-  for (int kk = 0; kk < 4; ++kk) {
-    const int o = (kk * 4 + (lane >> 4)) * TB + (lane & 15);
-    const double a = NEG ? -M[o] : M[o];
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, N[o], acc, 0, 0, 0);
-  }
-  return acc;
-}
-// accumulator element r of lane l is D(p, q), p = (l >> 4) + 4 r, q = l & 15
-__device__ __forceinline__ v4d tile_load(const double* T, int lane) {
-  v4d v;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) v[r] = T[(lane & 15) * TB + (lane >> 4) + 4 * r];
-  return v;
-}
-__device__ __forceinline__ void tile_store(double* T, v4d v, int lane) {
-#pragma unroll
-  for (int r = 0; r < 4; ++r) T[(lane & 15) * TB + (lane >> 4) + 4 * r] = v[r];
-}
-__device__ __forceinline__ v4d tile_load_t(const double* T, int lane) {  // loads D^T
-  v4d v;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) v[r] = T[((lane >> 4) + 4 * r) * TB + (lane & 15)];
-  return v;
-}
-__device__ __forceinline__ void tile_store_t(double* T, v4d v, int lane) {  // stores D^T
-#pragma unroll
-  for (int r = 0; r < 4; ++r) T[((lane >> 4) + 4 * r) * TB + (lane & 15)] = v[r];
-}
+constexpr int NTL = NB / TB;                      // 8 tile rows (tile primitives: chol_tiles.hpp)
 
 // LDS of one panel factorisation: 36 lower tiles, the failure word (and 1 KB to spare)
 constexpr size_t kPotrfLds = (size_t)(NTL * (NTL + 1) / 2) * kTile * 8 + 64 + NB * 8;
@@ -263,46 +220,11 @@ __device__ __forceinline__ void potrf_block(const DevP& P, double* A, int ld, in
   __syncthreads();
   HIPBA_CYCLES_AT(k, 1);
 
-  // (a) Cholesky of the 16x16 diagonal tile jd by one wave, in registers: lane r < 16 holds row r, the pivots and
-  // multipliers travel between lanes as wave-uniform scalars (v_readlane).  The tile's inverse comes out of the same
-  // instructions: lanes 16-31 start from the columns of the identity and go through the very same scalings and
-  // multiply-subtracts (forward substitution wants exactly the multipliers the factorisation broadcasts), so lane
-  // 16 + r ends up with column r of L^-1.  The factor goes straight to global memory; LDS keeps the inverse, which
-  // is what the panel below, the block inverse and the panel solve's caller need.
+  // (a) Cholesky of the 16x16 diagonal tile jd by one wave (tile_cholesky_inverse): the factor goes straight to
+  // global memory; LDS keeps the tile's inverse, which is what the panel below, the block inverse and the panel
+  // solve's caller need.
   auto diag_tile = [&](int jd) {
-    double* D = Lt + ltile(jd, jd);
-    const int r = lane & 15;
-    const bool inverse_half = (lane & 16) != 0;
-    double x[TB];
-#pragma unroll
-    for (int c = 0; c < TB; ++c) {
-      const double a = D[c * TB + r];
-      x[c] = inverse_half ? (c == r ? 1.0 : 0.0) : a;
-    }
-    bool bad = false;
-#pragma unroll
-    for (int c = 0; c < TB; ++c) {
-      const double d = bcast_lane(x[c], c);
-      if (!(d > 0.0) || !isfinite(d)) bad = true;
-      // 1/sqrt(d): hardware estimate + two Newton steps (full double precision, no division)
-      double inv = __builtin_amdgcn_rsq(d);
-      inv = inv * (1.5 - 0.5 * d * inv * inv);
-      inv = inv * (1.5 - 0.5 * d * inv * inv);
-      x[c] *= inv;
-#pragma unroll
-      for (int kc = c + 1; kc < TB; ++kc) x[kc] -= x[c] * bcast_lane(x[c], kc);  // lane kc < 16: L(kc, c)
-    }
-    if (bad) {
-      if (lane == 0) fail = 1;
-    } else if (lane < TB) {
-      double* G = Akk + (long long)(TB * jd) * ld + TB * jd + r;
-#pragma unroll
-      for (int c = 0; c < TB; ++c)
-        if (c <= r) G[(long long)c * ld] = x[c];
-    } else if (lane < 2 * TB) {
-#pragma unroll
-      for (int c = 0; c < TB; ++c) D[r * TB + c] = x[c];  // column r of the inverse (zero above the diagonal)
-    }
+    if (!tile_cholesky_inverse(Lt + ltile(jd, jd), Akk + (long long)(TB * jd) * ld + TB * jd, ld, lane) && lane == 0) fail = 1;
   };
   if (wave == 0) diag_tile(0);
   __syncthreads();

@@ -15,6 +15,7 @@
 #include <cfloat>
 
 #include "ba_device.hpp"
+#include "chol_tiles.hpp"
 #include "hipba_internal.hpp"
 
 namespace hipba {
@@ -1814,6 +1815,212 @@ __global__ __launch_bounds__(kSolveThreads) void k_window_solve_small(DevP P, Lm
 }
 #undef HIPBA_UIDX
 
+// The same solve for the larger of the small windows (a 30-keyframe window: n = 174), on the matrix cores.  S is held
+// in LDS as 16x16 tiles (chol_tiles.hpp), padded with an identity to a multiple of 16, and factored right-looking by
+// tile columns: wave 0 factors and inverts the diagonal tile (tile_cholesky_inverse), the panel below it is one
+// matrix-core product per tile with that inverse, and the trailing tiles are updated by the other seven waves while
+// wave 0 already updates and factors the next diagonal tile.  Forward and backward substitution are 16-wide
+// matrix-vector products by wave 0 with the tiles' inverses.  The 6x6-block version above walks 29 block columns of
+// ~5.6 k cycles each for such a window; this one 11 tile columns of ~7 k.
+constexpr int kTileSolveMinN = 48;  // windows from this size on take this kernel (smaller ones: the 6x6-block kernel above)
+__global__ __launch_bounds__(kSolveThreads) void k_window_solve_tiles(DevP P, LmParams lm, int fuse_pose_update) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* red = smem;                                  // [8]
+  int& fail = *reinterpret_cast<int*>(smem + 8);
+  const int w = blockIdx.x;
+  WinState* st = P.ws + w;
+  if (!st->active) return;
+  HIPBA_TICK(0);
+  const WinDesc wd = P.wd[w];
+  window_gradient_check(P, lm, wd, st, red, kFused);
+  HIPBA_TICK(1);
+  if (!st->active) return;
+  const int nb = wd.ncam;
+  if (nb == 0) return;
+  const int n = 6 * nb, nt = (n + TB - 1) / TB, ntl = nt * (nt + 1) / 2;
+  double* Lt = smem + 16;
+  double* zb = Lt + (size_t)ntl * kTile;               // right-hand side, then z = L^-1 b, then y
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const double* Sg = P.S + wd.S_off;
+  // packed upper 6x6 blocks (row-major inside a block) -> lower tiles.  The padding rows (n and beyond, all in the
+  // last tile row) are zero with a unit diagonal; the packed words are read in order (coalesced) and each is dropped
+  // at its place: entry (a, c) of block (bi, bj), bi < bj, is S(6 bj + c, 6 bi + a); of a diagonal block the entries
+  // a >= c.  (What lies above the diagonal inside a diagonal tile is never written: nothing below ever reads it.)
+  {
+    const int pad0 = n - TB * (nt - 1);  // first padding row inside the last tile row
+    for (int e = t; e < nt * kTile; e += kSolveThreads) {
+      const int bj = e >> 8, in = e & 255, pr = in & 15, qc = in >> 4;
+      if (pr >= pad0) Lt[ltile(nt - 1, bj) + in] = (bj == nt - 1 && pr == qc) ? 1.0 : 0.0;
+    }
+  }
+  {
+    // 14 groups of 36 lanes: a lane keeps its entry (a, c) and its group walks every 14th block, so the block's row
+    // and column are advanced, not recomputed; eight blocks' loads are in flight per lane
+    constexpr int kGroups = kSolveThreads / 36;
+    const int grp = t / 36, in = t - 36 * grp, a = in / 6, c = in - 6 * a;
+    const int nblk = nb * (nb + 1) / 2;
+    int bi = 0, off = grp;  // block (bi, bi + off)
+    if (grp < kGroups) {
+      for (int blk0 = grp; blk0 < nblk; blk0 += 8 * kGroups) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int blk = blk0 + u * kGroups;
+          v[u] = blk < nblk ? Sg[36ll * blk + in] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int blk = blk0 + u * kGroups;
+          if (blk < nblk) {
+            while (off >= nb - bi) { off -= nb - bi; ++bi; }
+            const int bj = bi + off;
+            if (bi != bj || a >= c) {
+              const int r = bi == bj ? 6 * bi + a : 6 * bj + c, cc = bi == bj ? 6 * bi + c : 6 * bi + a;
+              Lt[ltile(r / TB, cc / TB) + (cc % TB) * TB + (r % TB)] = v[u];
+            }
+          }
+          off += kGroups;
+        }
+      }
+    }
+  }
+  for (int i = t; i < TB * nt; i += kSolveThreads) zb[i] = i < n ? P.b[6ll * wd.cam_base + i] : 0.0;
+  if (t == 0) fail = 0;
+  __syncthreads();
+  HIPBA_TICK(2);
+  HIPBA_CYCLES(5);
+  if (wave == 0 && !tile_cholesky_inverse(Lt, nullptr, 0, lane) && lane == 0) fail = 1;
+  __syncthreads();
+  for (int j = 0; j < nt; ++j) {
+    if (fail) break;
+    // panel below the diagonal tile: L(i,j) = A(i,j) L(j,j)^-T (the result replaces the tile)
+    {
+      const double* Dinv = Lt + ltile(j, j);
+      for (int i = j + 1 + wave; i < nt; i += kSolveThreads / 64) {
+        double* T = Lt + ltile(i, j);
+        v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+        acc = mfma_tile<false>(Dinv, T, acc, lane);
+        tile_store_t(T, acc, lane);
+      }
+    }
+    __syncthreads();
+    // trailing tiles: A(i2,j2) -= L(i2,j) L(j2,j)^T.  Wave 0 takes the next diagonal tile alone and factors it at
+    // once (the longest single-wave job of a step) while the other waves share the remaining tiles.
+    if (wave == 0) {
+      if (j + 1 < nt) {
+        double* C = Lt + ltile(j + 1, j + 1);
+        v4d acc = tile_load_t(C, lane);
+        acc = mfma_tile<true>(Lt + ltile(j + 1, j), Lt + ltile(j + 1, j), acc, lane);
+        tile_store_t(C, acc, lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (!tile_cholesky_inverse(C, nullptr, 0, lane) && lane == 0) fail = 1;
+      }
+    } else {
+      int e = 0;
+      for (int i2 = j + 2; i2 < nt; ++i2) {
+        for (int j2 = j + 1; j2 <= i2; ++j2, ++e) {
+          if (e % (kSolveThreads / 64 - 1) != wave - 1) continue;
+          double* C = Lt + ltile(i2, j2);
+          v4d acc = tile_load_t(C, lane);
+          acc = mfma_tile<true>(Lt + ltile(j2, j), Lt + ltile(i2, j), acc, lane);
+          tile_store_t(C, acc, lane);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  HIPBA_TICK(3);
+  HIPBA_CYCLES(6);
+  if (fail) {
+    if (t == 0) st->solve_failed = 1;
+    return;
+  }
+  // L z = b, then L^T y = z, by wave 0: lane (p = lane >> 2, g = lane & 3) sums four columns of a 16x16
+  // matrix-vector product, and the four partial sums -- neighbouring lanes -- meet through two quad permutes.
+  // The diagonal tiles hold their inverses.
+  if (wave == 0) {
+    const int p = lane >> 2, g = lane & 3;
+    auto wave_sync = [] {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    // sum over the four lanes of a quad, in every lane: two DPP quad permutes per 32-bit half (no LDS round trip)
+    auto quad_xor = [](double v, int ctrl_is_xor2) {
+      const int lo = __double2loint(v), hi = __double2hiint(v);
+      const int plo = ctrl_is_xor2 ? __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xf, 0xf, false)
+                                   : __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xf, 0xf, false);
+      const int phi = ctrl_is_xor2 ? __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xf, 0xf, false)
+                                   : __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xf, 0xf, false);
+      return __hiloint2double(phi, plo);
+    };
+    auto groups_sum = [&](double v) {
+      v += quad_xor(v, 0);
+      v += quad_xor(v, 1);
+      return v;
+    };
+    double* vb = zb + TB * nt;  // 16 words: the vector a diagonal tile's inverse is applied to
+    for (int i = 0; i < nt; ++i) {
+      double acc = 0.0;
+#pragma unroll 4
+      for (int j = 0; j < i; ++j) {
+        const double* T = Lt + ltile(i, j);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc += T[(4 * g + q) * TB + p] * zb[TB * j + 4 * g + q];
+      }
+      const double v = zb[TB * i + p] - groups_sum(acc);   // every lane of the quad holds v(p)
+      if (g == 0) vb[p] = v;
+      wave_sync();
+      const double* D = Lt + ltile(i, i);
+      double zi = 0.0;
+      // z(p) = sum_q Linv(p, q) v(q)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) zi += D[(4 * g + q) * TB + p] * vb[4 * g + q];
+      zi = groups_sum(zi);
+      if (g == 0) zb[TB * i + p] = zi;
+      wave_sync();
+    }
+    for (int i = nt - 1; i >= 0; --i) {
+      double acc = 0.0;
+#pragma unroll 4
+      for (int k = i + 1; k < nt; ++k) {
+        const double* T = Lt + ltile(k, i);                 // (L(k,i)^T y_k)(p) = sum_q L(k,i)(q, p) y_k(q)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc += T[p * TB + 4 * g + q] * zb[TB * k + 4 * g + q];
+      }
+      const double v = zb[TB * i + p] - groups_sum(acc);
+      if (g == 0) vb[p] = v;
+      wave_sync();
+      const double* D = Lt + ltile(i, i);
+      double yi = 0.0;
+      // y(p) = sum_q Linv(q, p) v(q)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) yi += D[p * TB + 4 * g + q] * vb[4 * g + q];
+      yi = groups_sum(yi);
+      if (g == 0) zb[TB * i + p] = yi;
+      wave_sync();
+    }
+  }
+  __syncthreads();
+  HIPBA_TICK(4);
+  bool ok = true;
+  for (int i = t; i < n; i += kSolveThreads) {
+    const double v = zb[i];
+    P.yc[6ll * wd.cam_base + i] = v;
+    ok = ok && isfinite(v);
+  }
+  if (!ok) fail = 1;  // (several lanes may write the same value)
+  __syncthreads();
+  if (fail) {
+    if (t == 0) st->solve_failed = 1;
+    return;
+  }
+  if (!fuse_pose_update) return;
+  pose_update_window(P, w, Lt);  // the matrix words are free: two sums per wave go there
+}
+
 // gradient check alone, for windows whose reduced system is solved by the large-matrix path
 __global__ __launch_bounds__(kBlock) void k_window_gradient(DevP P, LmParams lm, int mode) {
   __shared__ double red[8];
@@ -1942,6 +2149,9 @@ hipError_t configure_lm_kernels() {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_gather),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)((kBlock / 64) * kGatherLds * 8));
   if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_window_solve_tiles), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          160 * 1024 - 256);
+  if (e != hipSuccess) return e;
   return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_window_solve_small),
                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
 }
@@ -2005,6 +2215,14 @@ hipError_t launch_point_schur(const DevP& P, const LmParams& lm, int small_ncam,
 }
 
 hipError_t launch_window_solve_small(const DevP& P, const LmParams& lm, int max_n, int fuse_pose_update, hipStream_t s) {
+  static const bool blocks_only = getenv("HIPBA_SMALL_SOLVER_BLOCKS") != nullptr;
+  static const int tile_min_n = getenv("HIPBA_TILE_MIN_N") ? atoi(getenv("HIPBA_TILE_MIN_N")) : kTileSolveMinN;
+  if (max_n >= tile_min_n && !blocks_only) {
+    const size_t nt = (size_t)(max_n + TB - 1) / TB;
+    const size_t lds = (16 + nt * (nt + 1) / 2 * kTile + TB * nt + TB) * 8;
+    hipLaunchKernelGGL(k_window_solve_tiles, dim3(P.n_windows), dim3(kSolveThreads), lds, s, P, lm, fuse_pose_update);
+    return hipGetLastError();
+  }
   const size_t nb = (size_t)(max_n + 5) / 6;
   const size_t lds = (16 + nb * (nb + 1) / 2 * kSmallBlk + 6 * nb) * 8;
   hipLaunchKernelGGL(k_window_solve_small, dim3(P.n_windows), dim3(kSolveThreads), lds, s, P, lm, fuse_pose_update);
