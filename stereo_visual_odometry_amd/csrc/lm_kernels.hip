@@ -2215,9 +2215,9 @@ hipError_t launch_point_schur(const DevP& P, const LmParams& lm, int small_ncam,
 }
 
 hipError_t launch_window_solve_small(const DevP& P, const LmParams& lm, int max_n, int fuse_pose_update, hipStream_t s) {
+  // development switch: HIPBA_SMALL_SOLVER_BLOCKS=1 keeps every window on the 6x6-block kernel (A/B timing)
   static const bool blocks_only = getenv("HIPBA_SMALL_SOLVER_BLOCKS") != nullptr;
-  static const int tile_min_n = getenv("HIPBA_TILE_MIN_N") ? atoi(getenv("HIPBA_TILE_MIN_N")) : kTileSolveMinN;
-  if (max_n >= tile_min_n && !blocks_only) {
+  if (max_n >= kTileSolveMinN && !blocks_only) {
     const size_t nt = (size_t)(max_n + TB - 1) / TB;
     const size_t lds = (16 + nt * (nt + 1) / 2 * kTile + TB * nt + TB) * 8;
     hipLaunchKernelGGL(k_window_solve_tiles, dim3(P.n_windows), dim3(kSolveThreads), lds, s, P, lm, fuse_pose_update);
