@@ -9,6 +9,7 @@ reduced camera matrix, its right-hand side and a handful of scalars are summed.
 """
 import ctypes as C
 import os
+import time
 
 import numpy as np
 import torch
@@ -54,7 +55,7 @@ class TorchComm:
     def _allreduce(self, ctx, buf, count, op, stream):
         try:
             if os.environ.get("HIPBA_TRACE_COMM"):
-                print("rank %d all-reduce #%d count %d op %d" % (self.rank, self.calls, count, op), flush=True)
+                print("%.3f rank %d all-reduce #%d count %d op %d" % (time.time() % 1000.0, self.rank, self.calls, count, op), flush=True)
             t = tensor_from_pointer(buf, count, self.device)
             rop = dist.ReduceOp.SUM if op == hipba.REDUCE_SUM else dist.ReduceOp.MAX
             if self.device.type == "cuda":
