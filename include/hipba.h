@@ -174,9 +174,12 @@ typedef struct hipba_device_problem_s* hipba_device_problem;
  * All-reduce over the ranks of a job, supplied by the caller (RCCL through
  * torch.distributed, or a wrapper around a raw ncclComm_t).  buf is DEVICE memory
  * holding count doubles; op is HIPBA_REDUCE_SUM or HIPBA_REDUCE_MAX; stream is the
- * hipStream_t the engine works on (the callee must order its collective after
+ * hipStream_t the call belongs to (the callee must order its collective after
  * work already queued on it, and leave the result visible to later work on it).
- * Return 0 on success.
+ * That is the engine's stream for most calls and a second stream of the handle for
+ * the pieces of the reduced matrix, which travel while the factorisation runs; the
+ * calls come from one thread, in the same order on every rank, and the callee need
+ * not wait for the host.  Return 0 on success.
  */
 enum { HIPBA_REDUCE_SUM = 0, HIPBA_REDUCE_MAX = 1 };
 typedef int (*hipba_allreduce_fn)(void* ctx, double* buf, size_t count, int op, void* stream);

@@ -18,7 +18,11 @@ def main():
     print("rank", rank, "up", flush=True)
     solver = hipba.Solver(0)
     n_points = int(sys.argv[1]) if len(sys.argv) > 1 else 40000  # 160000: every rank in the gathered elimination mode
-    prob, _, _ = scenes.bal_scale(seed=5, grid=(8, 10), n_points=n_points, depth_lo=5.0, depth_hi=30.0)
+    if len(sys.argv) > 2 and sys.argv[2] == "band":
+        # a band of tiles: gathered elimination into the dense matrix, tile exchange (pipelined unless HIPBA_EXCHANGE_CHUNKS=1)
+        prob, _, _ = scenes.bal_scale(seed=37, grid=(60, 4), n_points=n_points, depth_lo=5.0, depth_hi=15.0)
+    else:
+        prob, _, _ = scenes.bal_scale(seed=5, grid=(8, 10), n_points=n_points, depth_lo=5.0, depth_hi=30.0)
     comm = TorchComm(torch.device("cuda", 0))
     job = ShardedProblem(solver, prob, comm)
     opts = hipba.default_options(max_num_iterations=5)

@@ -101,23 +101,55 @@ hipError_t big_zero_lower(const DevP& P, const BigWork& W, bool enveloped, hipSt
   return hipGetLastError();
 }
 
-// Sharded solves exchange the reduced matrix as the 128x128 tiles inside its envelope, packed one after another
-// (to_buf: matrix -> buffer before the all-reduce; otherwise buffer -> matrix after it).  One workgroup per tile.
-__global__ __launch_bounds__(256) void k_env_tiles(DevP P, double* A, int ld, const int2* tiles, double* buf, int to_buf) {
+// Sharded solves exchange the reduced matrix as the 128x128 tiles inside its envelope, packed one after another.
+// One workgroup per tile.  kTilesPack / kTilesUnpack copy whole tiles (matrix -> buffer before a one-piece
+// all-reduce, buffer -> matrix after it).  kTilesTake / kTilesAdd are the pipelined exchange's pair: the rank's own
+// part moves to the buffer and leaves zeros behind, the factorisation starts on those, and the sum over the ranks is
+// added column chunk by column chunk (TileFeed).  Those two touch only what belongs to the matrix -- on and below
+// the diagonal, inside the leading n x n part -- because the rest of a tile (padding rows, the transposed factor
+// above the diagonal of a diagonal tile) is not the elimination's to sum.
+__global__ __launch_bounds__(256) void k_env_tiles(DevP P, double* A, int n, int ld, const int2* tiles, int tile0, double* buf,
+                                                   int mode) {
   if (!P.ws[0].active) return;
-  const int2 tl = tiles[blockIdx.x];  // (tile row, tile column)
+  const int2 tl = tiles[tile0 + blockIdx.x];  // (tile row, tile column)
   double* a = A + (long long)tl.y * NB * ld + (long long)tl.x * NB;
-  double* b = buf + (long long)blockIdx.x * NB * NB;
+  double* b = buf + (long long)(tile0 + blockIdx.x) * NB * NB;
   const int r = (threadIdx.x & 63) * 2;
+  const int row = tl.x * NB + r;
   for (int c = threadIdx.x >> 6; c < NB; c += 4) {
     double2* pa = reinterpret_cast<double2*>(a + (long long)c * ld + r);
     double2* pb = reinterpret_cast<double2*>(b + c * NB + r);
-    if (to_buf) *pb = *pa; else *pa = *pb;
+    if (mode == kTilesPack) {
+      *pb = *pa;
+    } else if (mode == kTilesUnpack) {
+      *pa = *pb;
+    } else {
+      const int col = tl.y * NB + c;
+      const bool in0 = row >= col && row < n && col < n, in1 = row + 1 >= col && row + 1 < n && col < n;
+      if (mode == kTilesTake) {
+        double2 v = *pa;
+        if (!in0) v.x = 0.0;
+        if (!in1) v.y = 0.0;
+        *pb = v;
+        if (in0 || in1) {
+          double2 z = *pa;  // what is not the matrix's stays as it is
+          if (in0) z.x = 0.0;
+          if (in1) z.y = 0.0;
+          *pa = z;
+        }
+      } else if (in0 || in1) {
+        double2 v = *pa;
+        const double2 w = *pb;
+        if (in0) v.x += w.x;
+        if (in1) v.y += w.y;
+        *pa = v;
+      }
+    }
   }
 }
-hipError_t big_env_tiles(const DevP& P, const BigWork& W, int n_tiles, double* buf, int to_buf, hipStream_t s) {
+hipError_t big_env_tiles(const DevP& P, const BigWork& W, int tile0, int n_tiles, double* buf, int mode, hipStream_t s) {
   if (n_tiles <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_env_tiles, dim3(n_tiles), dim3(256), 0, s, P, W.A, W.ld, (const int2*)W.tiles, buf, to_buf);
+  hipLaunchKernelGGL(k_env_tiles, dim3(n_tiles), dim3(256), 0, s, P, W.A, W.n, W.ld, (const int2*)W.tiles, tile0, buf, mode);
   return hipGetLastError();
 }
 
@@ -991,7 +1023,7 @@ hipError_t configure_dense_kernels() {
   return e;
 }
 
-hipError_t big_solve_cholesky(const DevP& P, const BigWork& W, const int* h_first, hipStream_t s) {
+hipError_t big_solve_cholesky(const DevP& P, const BigWork& W, const int* h_first, hipStream_t s, const TileFeed* feed) {
   const int n = W.n, npad = W.npad, nt = npad / NB;
   const int ld = (int)dense_ld(npad);  // one extra tile row: b^T rides along as row npad (see k_pad_init)
   const int ncam = n / 6;
@@ -1067,12 +1099,27 @@ hipError_t big_solve_cholesky(const DevP& P, const BigWork& W, const int* h_firs
     int dev = 0;
     return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 0;
   }();
+  // Pipelined exchange of a sharded solve: the launches of panel p factor diagonal block p + 1 as well, so every
+  // chunk that holds a tile column <= p + 1 is waited for and added before them.
+  int fed = 0;
+  hipError_t feed_error = hipSuccess;
+  auto feed_columns = [&](int upto) {
+    while (feed && fed < feed->n_chunks && feed->first_col[fed] <= upto && feed_error == hipSuccess) {
+      feed_error = hipStreamWaitEvent(s, feed->ready[fed], 0);
+      if (feed_error == hipSuccess)
+        feed_error = big_env_tiles(P, W, feed->tile_begin[fed], feed->tile_begin[fed + 1] - feed->tile_begin[fed],
+                                   const_cast<double*>(feed->packed), kTilesAdd, s);
+      ++fed;
+    }
+  };
+  feed_columns(0);
   hipLaunchKernelGGL(k_potrf_inv, dim3(1), dim3(256), kPotrfLds, s, P, W.A, ld, 0, W.Linv, W.LinvT);
   unsigned sync_arrivals = 0;  // two producers per fused band update
   const int resident = 2 * (max_resident > 0 ? max_resident : 256);  // two workgroups per CU
   for (int p0 = 0; p0 < nt; p0 += kOuter) {
     const int p1 = p0 + kOuter < nt ? p0 + kOuter : nt;
     for (int p = p0; p < p1; ++p) {
+      feed_columns(p + 1);
       const int rows = last[p] - p;  // tile rows below the diagonal block that panel p reaches
       const int strips = (NB / kTrsmRows) * rows + 1;
       hipLaunchKernelGGL(k_panel_solve, dim3(strips), dim3(256), kLdsTrsm, s, P, W.A, ld, p + 1, p * NB,
@@ -1092,6 +1139,8 @@ hipError_t big_solve_cholesky(const DevP& P, const BigWork& W, const int* h_firs
                          p0 * NB, (p1 - p0) * NB, m, W.Linv, W.LinvT, d_first, nt);
     }
   }
+  feed_columns(nt);  // (nothing left by now: the last column is due with panel nt - 2)
+  if (feed_error != hipSuccess) return feed_error;
   double* z = W.rhs + npad;
   double* y = W.rhs;
   if (nt <= max_resident) {

@@ -170,6 +170,11 @@ struct hipba_handle_s {
   // before / after the candidate cost pass), one set per slot of the poll ring; created on first use
   hipEvent_t phase_ev[4][4] = {};
   bool phase_ev_ready = false;
+  // pipelined exchange of sharded solves (TileFeed): a stream for the chunks' all-reduces, "the tiles are packed" on
+  // the engine's stream, "chunk c has arrived" on the exchange stream; created on first use
+  hipStream_t xchg_stream = nullptr;
+  hipEvent_t xchg_packed = nullptr;
+  hipEvent_t xchg_ready[kMaxFeedChunks] = {};
 };
 
 struct WinMeta {
@@ -1040,7 +1045,9 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
   DevP P = R->P;
   hipStream_t s = h->stream;
   const LmParams lm = make_lm(o);
-  const bool sharded = comm && comm->world_size > 1;
+  // (HIPBA_SHARD_SINGLE_RANK: a communicator of one rank takes the sharded path too -- every all-reduce is then the
+  // identity -- so that the whole exchange, the second stream included, can be rehearsed on one GPU)
+  const bool sharded = comm && (comm->world_size > 1 || (comm->world_size == 1 && getenv("HIPBA_SHARD_SINGLE_RANK")));
   if (sharded && P.n_windows != 1) return fail(HIPBA_ERR_INVALID_ARGUMENT, "sharded solves take exactly one window");
   if (sharded && !comm->allreduce) return fail(HIPBA_ERR_INVALID_ARGUMENT, "comm->allreduce is null");
   P.sharded = sharded ? 1 : 0;
@@ -1077,6 +1084,7 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
   // envelope's all-reduce as one more word (a shard small enough for the atomic elimination, or an envelope too
   // wide for the buffer, sends everybody down the packed path).
   int n_env_tiles = 0;
+  TileFeed feed;  // n_chunks > 0: the tiles travel while the factorisation runs
   if (sharded) direct = direct && env_ready;
   if (env_ready && sharded) {
     const size_t nt1 = R->env_first.size();
@@ -1091,10 +1099,16 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
     HIPBA_HIP(hipMemcpyAsync(R->big.first, R->env_first.data(), sizeof(int) * nt1, hipMemcpyHostToDevice, s));
     direct = neg[nt1] < 0.0;
     if (direct) {
+      // by tile column, the order the factorisation consumes them in (TileFeed)
       std::vector<int2> tiles;
+      std::vector<int> col_begin;
       const int nt = (int)nt1 - 1;
-      for (int i = 0; i < nt; ++i)
-        for (int j = R->env_first[i]; j <= i; ++j) tiles.push_back(make_int2(i, j));
+      for (int j = 0; j < nt; ++j) {
+        col_begin.push_back((int)tiles.size());
+        for (int i = j; i < nt; ++i)
+          if (R->env_first[i] <= j) tiles.push_back(make_int2(i, j));
+      }
+      col_begin.push_back((int)tiles.size());
       // (the merged envelope is the same on every rank, and so is this test)
       if ((long long)tiles.size() * kCholNB * kCholNB > R->S_doubles) {
         direct = false;
@@ -1102,6 +1116,35 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
         n_env_tiles = (int)tiles.size();
         HIPBA_HIP(hipMemcpyAsync(R->big.tiles, tiles.data(), sizeof(int2) * tiles.size(), hipMemcpyHostToDevice, s));
         HIPBA_HIP(hipStreamSynchronize(s));  // `tiles` goes out of scope
+        // The exchange in chunks of whole tile columns, about equal in tiles, that the factorisation picks up as it
+        // goes: the first chunk is small (the factorisation cannot start before it is there), HIPBA_EXCHANGE_CHUNKS=1
+        // brings back the exchange in one piece ahead of the factorisation.
+        const int want_chunks = getenv("HIPBA_EXCHANGE_CHUNKS") ? atoi(getenv("HIPBA_EXCHANGE_CHUNKS")) : 8;
+        const int n_chunks = std::min(std::min(want_chunks, (int)kMaxFeedChunks), nt);
+        if (n_chunks > 1) {
+          feed.n_chunks = 0;
+          feed.packed = P.S;
+          int col = 0;
+          for (int c = 0; c < n_chunks && col < nt; ++c) {
+            // chunk 0: half a share; the others split what is left evenly
+            const int left = n_env_tiles - col_begin[col];
+            const int share = c == 0 ? std::max(1, n_env_tiles / (2 * n_chunks)) : std::max(1, left / (n_chunks - c));
+            int end = col + 1;
+            while (end < nt && col_begin[end] - col_begin[col] < share) ++end;
+            if (c == n_chunks - 1) end = nt;
+            feed.first_col[feed.n_chunks] = col;
+            feed.tile_begin[feed.n_chunks] = col_begin[col];
+            ++feed.n_chunks;
+            col = end;
+          }
+          feed.tile_begin[feed.n_chunks] = n_env_tiles;
+          if (!h->xchg_stream) {
+            HIPBA_HIP(hipStreamCreateWithFlags(&h->xchg_stream, hipStreamNonBlocking));
+            HIPBA_HIP(hipEventCreateWithFlags(&h->xchg_packed, hipEventDisableTiming));
+            for (auto& ev : h->xchg_ready) HIPBA_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+          }
+          for (int c = 0; c < feed.n_chunks; ++c) feed.ready[c] = h->xchg_ready[c];
+        }
       }
     }
   }
@@ -1170,16 +1213,30 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
     if (!fuse_init) HIPBA_HIP(launch_init_reduced(P, lm, owner, s));
     HIPBA_HIP(launch_point_schur(P, lm, small_ncam, schur_parts, s));
     if (sharded) {
-      if (direct) {
-        HIPBA_HIP(big_env_tiles(P, R->big, n_env_tiles, P.S, 1, s));
+      const bool piped = direct && feed.n_chunks > 0 && solver == HIPBA_LINEAR_DENSE_CHOLESKY;
+      if (direct && !piped) {
+        HIPBA_HIP(big_env_tiles(P, R->big, 0, n_env_tiles, P.S, kTilesPack, s));
         AR(P.S, (size_t)n_env_tiles * kCholNB * kCholNB, HIPBA_REDUCE_SUM);
-        HIPBA_HIP(big_env_tiles(P, R->big, n_env_tiles, P.S, 0, s));
-      } else if (R->S_doubles) AR(P.S, (size_t)R->S_doubles, HIPBA_REDUCE_SUM);
+        HIPBA_HIP(big_env_tiles(P, R->big, 0, n_env_tiles, P.S, kTilesUnpack, s));
+      } else if (!direct && R->S_doubles) AR(P.S, (size_t)R->S_doubles, HIPBA_REDUCE_SUM);
       if (P.n_act_poses) AR(P.b, 6 * (size_t)P.n_act_poses, HIPBA_REDUCE_SUM);
       HIPBA_HIP(launch_window_gradient(P, lm, kReduce, s));
       AR(P.wsum, 1, HIPBA_REDUCE_MAX);
       AR(P.wsum + 1, 1, HIPBA_REDUCE_SUM);
       HIPBA_HIP(launch_window_gradient(P, lm, kDecide, s));
+      if (piped) {
+        // the matrix last: its chunks are summed on the exchange stream while this stream factors what has arrived
+        HIPBA_HIP(big_env_tiles(P, R->big, 0, n_env_tiles, P.S, kTilesTake, s));
+        HIPBA_HIP(hipEventRecord(h->xchg_packed, s));
+        HIPBA_HIP(hipStreamWaitEvent(h->xchg_stream, h->xchg_packed, 0));
+        for (int c = 0; c < feed.n_chunks; ++c) {
+          const size_t t0 = (size_t)feed.tile_begin[c], t1 = (size_t)feed.tile_begin[c + 1];
+          if (comm->allreduce(comm->ctx, P.S + t0 * kCholNB * kCholNB, (t1 - t0) * kCholNB * kCholNB, HIPBA_REDUCE_SUM,
+                              (void*)h->xchg_stream))
+            return fail(HIPBA_ERR_COMM, "all-reduce callback failed");
+          HIPBA_HIP(hipEventRecord(feed.ready[c], h->xchg_stream));
+        }
+      }
     }
     if (small && !sharded) {
       HIPBA_HIP(launch_window_solve_small(P, lm, max_n, 1, s));  // also forms the candidate poses
@@ -1191,7 +1248,8 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
       } else if (solver == HIPBA_LINEAR_PCG) {
         HIPBA_HIP(big_solve_pcg(P, R->big, o.pcg_max_iterations, o.pcg_tolerance, s));
       } else {
-        HIPBA_HIP(big_solve_cholesky(P, R->big, env_ready ? R->env_first.data() : nullptr, s));
+        HIPBA_HIP(big_solve_cholesky(P, R->big, env_ready ? R->env_first.data() : nullptr, s,
+                                     sharded && direct && feed.n_chunks > 0 ? &feed : nullptr));
       }
     }
     HIPBA_HIP(launch_backsub(P, lm, s));
@@ -1444,6 +1502,10 @@ int hipba_destroy(hipba_handle h) {
     if (h->staging) (void)hipHostFree(h->staging);
     if (h->h_count) (void)hipHostFree(h->h_count);
     for (int i = 0; i < 4; ++i) if (h->poll_ev[i]) (void)hipEventDestroy(h->poll_ev[i]);
+    if (h->xchg_stream) (void)hipStreamSynchronize(h->xchg_stream);
+    if (h->xchg_packed) (void)hipEventDestroy(h->xchg_packed);
+    for (auto& ev : h->xchg_ready) if (ev) (void)hipEventDestroy(ev);
+    if (h->xchg_stream) (void)hipStreamDestroy(h->xchg_stream);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return HIPBA_OK;

@@ -55,14 +55,30 @@ struct BigWork {
 constexpr int kCholNB = 128;
 size_t big_work_bytes(int n, int ncam);
 void big_work_bind(BigWork& W, int n, int ncam, void* base);
+// A sharded solve may hand the factorisation the other ranks' part of the matrix while it runs: the packed tiles
+// (W.tiles, ordered by tile column) are summed over the ranks in chunks of whole tile columns on a second stream, and
+// the factorisation adds a chunk to its matrix just before the first panel that needs one of its columns.  That is
+// exact because every step of a right-looking factorisation before that point only ever ADDS to those columns.
+constexpr int kMaxFeedChunks = 16;
+struct TileFeed {
+  int n_chunks = 0;
+  int first_col[kMaxFeedChunks] = {};       // first tile column of chunk c (ascending; chunk 0 starts at column 0)
+  int tile_begin[kMaxFeedChunks + 1] = {};  // tiles [tile_begin[c], tile_begin[c + 1]) of W.tiles / of the buffer
+  hipEvent_t ready[kMaxFeedChunks] = {};    // recorded behind chunk c's all-reduce
+  const double* packed = nullptr;           // the buffer the chunks arrive in
+};
 // Cholesky: S (packed, P.S) y = b (P.b) -> P.yc; marks ws.solve_failed when S is not positive definite
 // h_first: the envelope (host copy of W.first, camera_order.hpp), or null for a dense factorisation
-hipError_t big_solve_cholesky(const DevP& P, const BigWork& W, const int* h_first, hipStream_t s);
+hipError_t big_solve_cholesky(const DevP& P, const BigWork& W, const int* h_first, hipStream_t s,
+                              const TileFeed* feed = nullptr);
 // zeroes the lower triangle of W.A (enveloped: only inside the envelope in W.first): for solves whose elimination
 // writes the blocks of S straight into it (DevP::dense_S)
 hipError_t big_zero_lower(const DevP& P, const BigWork& W, bool enveloped, hipStream_t s);
-// copies the tiles listed in W.tiles between the dense matrix and a packed buffer (sharded solves' exchange)
-hipError_t big_env_tiles(const DevP& P, const BigWork& W, int n_tiles, double* buf, int to_buf, hipStream_t s);
+// moves tiles [tile0, tile0 + n_tiles) of W.tiles between the dense matrix and a packed buffer (sharded solves'
+// exchange): kTilesUnpack buffer -> matrix, kTilesPack matrix -> buffer, kTilesTake matrix -> buffer and zeroes in
+// the matrix, kTilesAdd matrix += buffer (the last two: on and below the diagonal of the leading n x n part only)
+enum { kTilesUnpack = 0, kTilesPack = 1, kTilesTake = 2, kTilesAdd = 3 };
+hipError_t big_env_tiles(const DevP& P, const BigWork& W, int tile0, int n_tiles, double* buf, int mode, hipStream_t s);
 // block-Jacobi preconditioned conjugate gradients on the packed S
 hipError_t big_solve_pcg(const DevP& P, const BigWork& W, int max_iter, double tol, hipStream_t s);
 

@@ -300,12 +300,17 @@ class DeviceProblem:
         _check(self.solver._lib.hipba_solve_device(self.solver._h, self._h, C.byref(o), summ))
         return [_summary_dict(summ[w], logs[w] if log else None) for w in range(n)]
 
-    def solve_sharded(self, comm, options=None):
+    def solve_sharded(self, comm, options=None, log=False):
         o = options if options is not None else default_options()
         summ = CSummary()
+        lg = None
+        if log:
+            lg = (CIteration * (o.max_num_iterations + 2))()
+            summ.iteration_log = lg
+            summ.iteration_log_capacity = len(lg)
         _check(self.solver._lib.hipba_solve_device_sharded(self.solver._h, self._h, C.byref(comm), C.byref(o),
                                                            C.byref(summ)))
-        return _summary_dict(summ)
+        return _summary_dict(summ, lg)
 
     def download(self, window=0):
         p = self.problems[window]

@@ -49,6 +49,9 @@ class TorchComm:
         self.world_size = dist.get_world_size(group)
         self.calls = 0
         self.bytes = 0
+        # HIPBA_COMM_HOST_SYNC: the host waits for the stream before and after every collective (rehearsals of several
+        # ranks on ONE device through gloo, whose staging streams otherwise interleave with the engine's two)
+        self.host_sync = bool(os.environ.get("HIPBA_COMM_HOST_SYNC"))
         self._cb = hipba.ALLREDUCE_FN(self._allreduce)  # keep a reference: ctypes callbacks are not owned by C
         self.c = hipba.CComm(self._cb, None, self.rank, self.world_size)
 
@@ -61,7 +64,11 @@ class TorchComm:
             if self.device.type == "cuda":
                 ext = torch.cuda.ExternalStream(int(stream), device=self.device)
                 with torch.cuda.stream(ext):
+                    if self.host_sync:
+                        ext.synchronize()
                     dist.all_reduce(t, op=rop, group=self.group)
+                    if self.host_sync:
+                        ext.synchronize()
             else:
                 dist.all_reduce(t, op=rop, group=self.group)
             self.calls += 1

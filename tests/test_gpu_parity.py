@@ -314,9 +314,10 @@ def test_full_size_properties_bal_scale(solver):
     dp.free()
 
 
-def run_threaded_ranks(prob, opts, world=2, timeout=300):
+def run_threaded_ranks(prob, opts, world=2, timeout=300, trace=None):
     """`world` ranks on one GPU (threads, each with its own handle and stream); the all-reduce callback stages
-    through host memory.  Returns [(summary, poses, points, lo, hi)] per rank."""
+    through host memory.  Returns [(summary, poses, points, lo, hi)] per rank.  trace: a list that receives rank 0's
+    calls as (count, op, on the engine's stream?)."""
     import ctypes as C
     hip = C.CDLL("libamdhip64.so")  # the callback stages through host memory with plain HIP copies
     hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
@@ -325,11 +326,14 @@ def run_threaded_ranks(prob, opts, world=2, timeout=300):
     order = hipba.pose_order(prob)  # chosen once on the whole problem, the same for every rank
     slots = [None] * world
     results = [None] * world
+    streams = [None] * world
 
     def make_cb(rank):
         def cb(ctx, buf, count, op, stream):
             try:
                 assert hip.hipStreamSynchronize(stream) == 0
+                if trace is not None and rank == 0:
+                    trace.append((int(count), int(op), int(stream or 0) == int(streams[0] or 0)))
                 mine = np.empty(count, dtype=np.float64)
                 assert hip.hipMemcpy(mine.ctypes.data, buf, 8 * count, 2) == 0   # device to host
                 slots[rank] = mine
@@ -345,6 +349,7 @@ def run_threaded_ranks(prob, opts, world=2, timeout=300):
 
     def run(rank):
         sv = hipba.Solver(0)
+        streams[rank] = sv.stream
         shard, (lo, hi) = scenes.shard_by_point(prob, rank, world)
         dp = sv.upload_shard(shard, order)
         cb = make_cb(rank)
@@ -413,10 +418,10 @@ def test_c4_true_size_properties_and_two_rank_shards():
 
 
 def test_sharded_solve_with_gathered_elimination_equals_unsharded():
-    """The multi-GPU configuration of the BAL-scale problem in small: every shard is large enough (more than 20
-    cameras, at least 2M observation pairs) for the per-block gather, whose blocks then go to the packed reduced
-    matrix (zeroed every iteration, diagonal blocks added atomically onto the owner's U + D^2, summed over ranks
-    and unpacked for the factorisation) instead of straight into the dense matrix."""
+    """Every shard is large enough (more than 20 cameras, at least 2M observation pairs) for the per-block gather, but
+    the reduced matrix is dense and its tiles do not fit the packed buffer: the blocks go to the packed reduced matrix
+    (zeroed every iteration, diagonal blocks added atomically onto the owner's U + D^2, summed over ranks and unpacked
+    for the factorisation) instead of straight into the dense matrix."""
     prob, _, _ = scenes.bal_scale(seed=37, grid=(10, 10), n_points=120000, depth_lo=5.0, depth_hi=30.0)
     opts = lambda: hipba.default_options(max_num_iterations=5)
     ref = prob.copy()
@@ -429,6 +434,78 @@ def test_sharded_solve_with_gathered_elimination_equals_unsharded():
         assert abs(s["final_cost"] - s_ref["final_cost"]) <= 1e-9 * s_ref["final_cost"]
         assert np.abs(poses - ref.poses).max() <= 1e-8
         assert np.abs(pts - ref.points[lo:hi]).max() <= 1e-7
+
+
+def banded_scene():
+    """A long, narrow camera grid with shallow landmarks: co-visibility reaches 47 cameras of 240, the reduced matrix
+    is a band of 128x128 tiles -- the multi-GPU configuration of the BAL-scale problem in small (gathered elimination
+    into the dense matrix, exchange of the tiles inside the envelope)."""
+    return scenes.bal_scale(seed=37, grid=(60, 4), n_points=120000, depth_lo=5.0, depth_hi=15.0)[0]
+
+
+def test_sharded_tile_exchange_in_one_piece_and_pipelined(monkeypatch):
+    """Both forms of the tile exchange of a sharded solve: in one piece ahead of the factorisation
+    (HIPBA_EXCHANGE_CHUNKS=1), and in chunks of tile columns on a second stream that the factorisation adds to its
+    matrix as it reaches them (the default)."""
+    prob = banded_scene()
+    opts = lambda: hipba.default_options(max_num_iterations=5)
+    ref = prob.copy()
+    sv = hipba.Solver(0)
+    s_ref = sv.solve(ref, opts())
+    sv.close()
+    traces = {}
+    for chunks in ("1", None):
+        if chunks is None:
+            monkeypatch.delenv("HIPBA_EXCHANGE_CHUNKS", raising=False)
+        else:
+            monkeypatch.setenv("HIPBA_EXCHANGE_CHUNKS", chunks)
+        trace = traces[chunks] = []
+        results = run_threaded_ranks(prob, opts, trace=trace)
+        for s, poses, pts, lo, hi in results:
+            assert s["termination_type"] == s_ref["termination_type"] and s["num_iterations"] == s_ref["num_iterations"]
+            assert abs(s["final_cost"] - s_ref["final_cost"]) <= 1e-9 * s_ref["final_cost"]
+            assert np.abs(poses - ref.poses).max() <= 1e-8
+            assert np.abs(pts - ref.points[lo:hi]).max() <= 1e-7
+    # one piece: every call on the engine's stream, the tiles as the largest one
+    assert all(on_engine for _, _, on_engine in traces["1"])
+    tile_words = max(count for count, _, _ in traces["1"])
+    assert tile_words % (128 * 128) == 0
+    # chunks: the same words per iteration, on another stream, in more than one call
+    n_it = sum(1 for count, _, _ in traces["1"] if count == tile_words)
+    off = [count for count, _, on_engine in traces[None] if not on_engine]
+    assert len(off) > n_it and sum(off) == n_it * tile_words and all(c % (128 * 128) == 0 for c in off)
+    assert all(count < tile_words for count, _, on_engine in traces[None] if on_engine)
+
+
+def test_pipelined_exchange_with_the_native_rccl_communicator_single_rank(monkeypatch):
+    """The chunked exchange through the library's own RCCL communicator, as far as one GPU allows: with
+    HIPBA_SHARD_SINGLE_RANK a communicator of one rank goes through the whole sharded path (every all-reduce is the
+    identity): ncclAllReduce of the chunks on the exchange stream beside the factorisation's kernels on the engine's,
+    the events between the two.  Must reproduce the plain solve."""
+    prob = banded_scene()
+    opts = lambda: hipba.default_options(max_num_iterations=5)
+    sv = hipba.Solver(0)
+    ref = prob.copy()
+    s_ref = sv.solve(ref, opts())
+    comm = hipba.RcclComm(0, hipba.RcclComm.unique_id(), 0, 1)
+    try:
+        calls = {}
+        for chunks in ("1", "8"):
+            monkeypatch.setenv("HIPBA_SHARD_SINGLE_RANK", "1")
+            monkeypatch.setenv("HIPBA_EXCHANGE_CHUNKS", chunks)
+            dp = sv.upload_shard(prob, hipba.pose_order(prob))
+            before = comm.calls
+            s = dp.solve_sharded(comm.c, opts())
+            calls[chunks] = comm.calls - before
+            poses, pts = dp.download()
+            dp.free()
+            assert s["termination_type"] == s_ref["termination_type"] and s["num_iterations"] == s_ref["num_iterations"]
+            assert abs(s["final_cost"] - s_ref["final_cost"]) <= 1e-9 * s_ref["final_cost"]
+            assert np.abs(poses - ref.poses).max() <= 1e-8 and np.abs(pts - ref.points).max() <= 1e-7
+        assert calls["8"] > calls["1"] > 0
+    finally:
+        comm.close()
+        sv.close()
 
 
 def test_time_breakdown_is_reported_on_request(solver):
