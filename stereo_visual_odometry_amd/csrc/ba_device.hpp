@@ -141,7 +141,7 @@ struct DevP {
   // gathered accumulation of the reduced matrix (one large window): every 6x6 block of S sums the products of
   // its observation pairs, listed in destination order; a product is recomputed from the landmark's record
   // and the two poses, so nothing per observation is kept in HBM.  Null when fp64 atomics are used instead.
-  const uint2* pair_pt;           // [n_pairs] (landmark, (row slot << 16) | column slot)
+  const uint2* pair_pt;           // [n_pairs] (landmark | self pair << 31, (row slot << 16) | column slot)
   const uint2* pair_obs;          // [n_pairs] (observation i, observation j): where a robust loss reads its weights
   const long long* chunk_start;   // [2 * n_chunks] (begin, end) pair ranges cut at destination boundaries, one wave
                                   // each, longest first

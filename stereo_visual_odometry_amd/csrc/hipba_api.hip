@@ -696,7 +696,9 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
     for_each_pair([&](int pp, long long oi, long long oj, int si, int sj, long long dst) {
       const long long at = cur[dst]++;
       pair_obs[at] = make_uint2((unsigned)oi, (unsigned)oj);
-      pair_pt[at] = make_uint2((unsigned)pp, ((unsigned)si << 16) | (unsigned)sj);
+      // bit 31 of the landmark word: the pair of an observation with itself, which also carries the observation's
+      // term of the reduced right-hand side (k_schur_gather)
+      pair_pt[at] = make_uint2((unsigned)pp | (oi == oj ? 0x80000000u : 0u), ((unsigned)si << 16) | (unsigned)sj);
     });
     // one wave per chunk of about kGatherChunk pairs; a chunk holds whole destinations, so every block of S
     // has exactly one writer

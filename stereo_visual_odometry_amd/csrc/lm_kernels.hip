@@ -315,47 +315,6 @@ __global__ __launch_bounds__(kBlock) void k_camera_blocks(DevP P, LmParams lm, i
   }
 }
 
-// reduced right-hand side, camera by camera: b_c -= sum over the camera's observations of variable landmarks of
-// Jc^T Jp V^-1 g_p (= Y g_p), with V^-1 g_p as k_point_schur left it in the landmark's record.  One workgroup and one writer per
-// pose: no atomics, fixed order.  Used with the gathered accumulation of S.
-__global__ __launch_bounds__(kBlock) void k_camera_rhs(DevP P, LmParams lm) {
-  __shared__ double red[6 * 4];
-  const int g = blockIdx.x;
-  const int c = P.slot_pose[g];
-  const int w = P.pose_window[c];
-  const WinState* st = P.ws + w;
-  if (!st->active) return;
-  const int sel = st->sel;
-  const CameraK K = P.wd[w].K;
-  double pose[7];
-#pragma unroll
-  for (int i = 0; i < 7; ++i) pose[i] = P.poses[sel][7ll * c + i];
-  double sc[6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) sc[i] = P.scale_c[6ll * g + i];
-  double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  const long long o1 = P.cm_start[g + 1];
-  for (long long o = P.cm_start[g] + threadIdx.x; o < o1; o += kBlock) {
-    const int pp = P.cm_dp[o];
-    if (pp >= P.n_pm_points) continue;  // constant landmark: nothing was eliminated
-    const double* rec = P.prec + 16ll * pp;  // the landmark's record: p in words 0-2, scale_p o (V^-1 g_p) in 12-14
-    const double p[3] = {rec[0], rec[1], rec[2]};
-    const double2 uv = reinterpret_cast<const double2*>(P.cm_uv)[o];
-    double r[2], Jc[12], Jp[6];
-    eval_obs<true>(K, lm, pose, p, uv.x, uv.y, sc, nullptr, r, Jc, Jp);  // landmark columns unscaled: the record carries scale_p
-    const double t0 = rec[12], t1 = rec[13], t2 = rec[14];
-    const double m0 = Jp[0] * t0 + Jp[1] * t1 + Jp[2] * t2;
-    const double m1 = Jp[3] * t0 + Jp[4] * t1 + Jp[5] * t2;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) acc[i] += Jc[i] * m0 + Jc[6 + i] * m1;
-  }
-  block_sum<6>(acc, red);
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int i = 0; i < 6; ++i) P.b[6ll * g + i] -= acc[i];
-  }
-}
-
 // Jacobi scaling of the pose columns, computed once at iteration 0 from the unscaled blocks
 // (Ceres: scale = 1 / (1 + sqrt(squared column norm))), then folded into U and g.
 __global__ void k_make_scale_c(DevP P, int jacobi) {
@@ -655,7 +614,7 @@ __global__ __launch_bounds__(kBlock) void k_point_schur(DevP P, LmParams lm, int
           for (int i = 0; i < 3; ++i) { rec[i] = p[i]; rec[3 + i] = P.scale_p[3ll * pp + i]; }
 #pragma unroll
           for (int i = 0; i < 6; ++i) rec[6 + i] = Vi[i];
-          // scale_p o (V^-1 g_p) rides in the spare words: k_camera_rhs finds everything about a landmark in one line
+          // scale_p o (V^-1 g_p) rides in the spare words: k_schur_gather forms the reduced right-hand side from it
           rec[12] = P.scale_p[3ll * pp] * (Vi[0] * gpv[0] + Vi[1] * gpv[1] + Vi[2] * gpv[2]);
           rec[13] = P.scale_p[3ll * pp + 1] * (Vi[1] * gpv[0] + Vi[3] * gpv[1] + Vi[4] * gpv[2]);
           rec[14] = P.scale_p[3ll * pp + 2] * (Vi[2] * gpv[0] + Vi[4] * gpv[1] + Vi[5] * gpv[2]);
@@ -683,7 +642,7 @@ __global__ __launch_bounds__(kBlock) void k_point_schur(DevP P, LmParams lm, int
           Z[3 * i + 1] = w1 * c11 + w2 * c21;
           Z[3 * i + 2] = w2 * c22;
         }
-        // b_c -= Y g_p = Z (C^T g_p) (gathered mode leaves this to k_camera_rhs: one writer per pose instead of atomics)
+        // b_c -= Y g_p = Z (C^T g_p) (gathered mode leaves this to k_schur_gather: one writer per pose instead of atomics)
         if (MODE != 2) {
           const double u0 = c00 * gpv[0] + c10 * gpv[1] + c20 * gpv[2], u1 = c11 * gpv[1] + c21 * gpv[2], u2 = c22 * gpv[2];
           double* bdst = SMALL ? accB + 6 * slot : P.b + 6ll * (wd.cam_base + slot);
@@ -778,9 +737,9 @@ constexpr int kGatherLds = 36 * kGatherRow + 16;  // doubles per wave (the recor
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
   } while (0)
 
-// scaled Jacobians of one observation from the camera table row (R^T, R^T t, column scales) and the landmark
-__device__ __forceinline__ void gather_side(const CameraK& K, const double* cam, const double* p,
-                                            const double* sp, double* Jc, double* Jp) {
+// Jacobians of one observation from the camera table row (R^T, R^T t, column scales) and the landmark: the pose
+// columns scaled, the landmark columns not yet
+__device__ __forceinline__ void gather_side(const CameraK& K, const double* cam, const double* p, double* Jc, double* Jp) {
   double Rt[9], pc[3];
 #pragma unroll
   for (int i = 0; i < 9; ++i) Rt[i] = cam[i];
@@ -789,8 +748,6 @@ __device__ __forceinline__ void gather_side(const CameraK& K, const double* cam,
   projection_jacobians(K, Rt, pc, Jc, Jp);
 #pragma unroll
   for (int i = 0; i < 6; ++i) { const double s = cam[12 + i]; Jc[i] *= s; Jc[6 + i] *= s; }
-#pragma unroll
-  for (int i = 0; i < 3; ++i) { Jp[i] *= sp[i]; Jp[3 + i] *= sp[i]; }
 }
 
 __global__ __launch_bounds__(kBlock) void k_schur_gather(DevP P, LmParams lm) {
@@ -816,9 +773,19 @@ __global__ __launch_bounds__(kBlock) void k_schur_gather(DevP P, LmParams lm) {
   double acc = 0.0;
   double* const dense = P.dense_S;
   const int er = e / 6, ec = e % 6;
+  // word of the right-hand side a lane sums in a diagonal destination (see the products below), or -1
+  const int e_rhs = (lane < 36 && er >= 1 && er <= 3 && ec < er) ? er * (er - 1) / 2 + ec : -1;
+  double* const bw = P.b + 6ll * P.wd[0].cam_base;
   auto flush = [&]() {
     if (cur >= 0 && lane < 36) {
-      if (dense) {
+      // (a diagonal block is symmetric: the packed matrix, which keeps all of it, gets the words that carry the
+      // right-hand side from their mirror images)
+      double mirror = 0.0;
+      if (cur_diag && !dense) mirror = __shfl(acc, 6 * ec + er);  // (wave-uniform condition)
+      if (cur_diag && e_rhs >= 0) {
+        bw[6 * cur_a + e_rhs] -= acc;  // this wave is the only writer of the pose's six words
+        if (!dense) atomic_add_f64(S + 36ll * cur + e, -mirror);
+      } else if (dense) {
         // straight into the dense lower triangle: consecutive destinations of a row slot are consecutive 48-byte
         // pieces of the same six columns
         double* dst = dense + (long long)(6 * cur_a + er) * P.dense_ld + 6 * cur_b + ec;
@@ -840,7 +807,7 @@ __global__ __launch_bounds__(kBlock) void k_schur_gather(DevP P, LmParams lm) {
   auto load_records = [&](const uint2& ent, double2* rv) {
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
-      const unsigned ppu = __shfl(ent.x, 8 * m + (lane >> 3));
+      const unsigned ppu = __shfl(ent.x, 8 * m + (lane >> 3)) & 0x7fffffffu;  // (bit 31: a pair of an observation with itself)
       rv[m] = reinterpret_cast<const double2*>(P.prec + 16ll * ppu)[lane & 7];
     }
   };
@@ -862,11 +829,13 @@ __global__ __launch_bounds__(kBlock) void k_schur_gather(DevP P, LmParams lm) {
         camA[2 * i] = x.x; camA[2 * i + 1] = x.y; camB[2 * i] = y.x; camB[2 * i + 1] = y.y;
       }
     }
-    double wgt = 1.0;
+    double wgt = 1.0, wgt_rhs = 1.0;
     if (robust) {
       const uint2 po = P.pair_obs[q + (live ? lane : 0)];
-      wgt = P.fw[po.x] * P.fw[po.y];
+      const double fa = P.fw[po.x];
+      wgt = fa * P.fw[po.y];
       wgt *= wgt;
+      wgt_rhs = fa * fa;
     }
     const uint2 pe_next2 = load_entry(q + 128);
     double2 rv_next[8];
@@ -878,13 +847,32 @@ __global__ __launch_bounds__(kBlock) void k_schur_gather(DevP P, LmParams lm) {
       w[0] = rv[m].x; w[1] = rv[m].y;
     }
     HIPBA_WAVE_SYNC();
-    double rec[12];
+    double rec[15];
 #pragma unroll
-    for (int k = 0; k < 12; ++k) rec[k] = sT[lane * kGatherRec + k];
+    for (int k = 0; k < 15; ++k) rec[k] = sT[lane * kGatherRec + k];
     HIPBA_WAVE_SYNC();  // records are in registers; the words are free for the products
     double JcA[12], JpA[6], JcB[12], JpB[6];
-    gather_side(K, camA, rec, rec + 3, JcA, JpA);
-    gather_side(K, camB, rec, rec + 3, JcB, JpB);
+    gather_side(K, camA, rec, JcA, JpA);
+    gather_side(K, camB, rec, JcB, JpB);
+    const int diag = a == b ? 1 : 0;
+    // A pair of an observation with itself also carries that observation's term of the reduced right-hand side,
+    // Jc^T Jp (V^-1 g_p) with scale_p o (V^-1 g_p) from the record and the landmark columns still unscaled.  Only
+    // the upper triangle of a diagonal block is kept, so six of the words below its diagonal carry these instead
+    // and are summed with the block, in the same fixed order, by the same single writer.
+    double bq[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    const bool self = (pe.x >> 31) != 0u;
+    if (__any(self)) {
+      const double ws = self ? wgt_rhs : 0.0;  // two different observations by one pose: the block only
+      const double m0 = (JpA[0] * rec[12] + JpA[1] * rec[13] + JpA[2] * rec[14]) * ws;
+      const double m1 = (JpA[3] * rec[12] + JpA[4] * rec[13] + JpA[5] * rec[14]) * ws;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) bq[k] = JcA[k] * m0 + JcA[6 + k] * m1;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const double sp = rec[3 + i];
+      JpA[i] *= sp; JpA[3 + i] *= sp; JpB[i] *= sp; JpB[3 + i] *= sp;
+    }
     const double* Vi = rec + 6;
     double M[4];
 #pragma unroll
@@ -904,10 +892,14 @@ __global__ __launch_bounds__(kBlock) void k_schur_gather(DevP P, LmParams lm) {
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
 #pragma unroll
-      for (int c = 0; c < 6; ++c) sT[(6 * r + c) * kGatherRow + lane] = JcA[r] * T[c] + JcA[6 + r] * T[6 + c];
+      for (int c = 0; c < 6; ++c) {
+        double val = JcA[r] * T[c] + JcA[6 + r] * T[6 + c];
+        // rows 1-3 below the diagonal: (1,0) (2,0) (2,1) (3,0) (3,1) (3,2) -> right-hand side words 0..5
+        if (r >= 1 && r <= 3 && c < r && diag) val = bq[r * (r - 1) / 2 + c];
+        sT[(6 * r + c) * kGatherRow + lane] = val;
+      }
     }
     const int dest = live ? (int)tri_index(a, b, ncam) : -1;
-    const int diag = a == b ? 1 : 0;
     HIPBA_WAVE_SYNC();
     // the batch's runs of one destination, from a ballot of the run heads.  Lanes 0-35 sum a run in list order,
     // sixteen columns per step with the next run's first sixteen already on their way from LDS; columns
@@ -2199,7 +2191,6 @@ hipError_t launch_point_schur(const DevP& P, const LmParams& lm, int small_ncam,
     const size_t gather_lds = (size_t)(kBlock / 64) * kGatherLds * 8;
     const unsigned grid = (unsigned)((P.n_chunks + kBlock / 64 - 1) / (kBlock / 64));
     if (grid) hipLaunchKernelGGL(k_schur_gather, dim3(grid), dim3(kBlock), gather_lds, s, P, lm);
-    hipLaunchKernelGGL(k_camera_rhs, dim3(P.n_act_poses), dim3(kBlock), 0, s, P, lm);
   } else if (small_ncam > 0) {
     if (parts < 1) parts = 1;
     const size_t lds = schur_lds_bytes(small_ncam, false);
