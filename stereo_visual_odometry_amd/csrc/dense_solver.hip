@@ -156,13 +156,18 @@ hipError_t big_env_tiles(const DevP& P, const BigWork& W, int tile0, int n_tiles
 // rows beyond n: identity on the padded diagonal, and b^T as row npad -- the first row of one extra tile row.
 // Factorising [S; b^T] row-wise like any other row block leaves z^T = (L^-1 b)^T in that row: the forward
 // substitution costs no launches of its own.
-__global__ void k_pad_init(DevP P, double* A, int n, int npad, int ld, unsigned* sync, unsigned* flags) {
+// "not written yet" in the solution vector of the one-launch backward sweep (a NaN no arithmetic produces: the
+// sweep stores the canonical quiet NaN for any NaN of its own)
+constexpr unsigned long long kNotYet = 0x7ff8dead7ff8deadull;
+
+__global__ void k_pad_init(DevP P, double* A, int n, int npad, int ld, unsigned* sync, unsigned* flags, double* y_not_yet) {
   if (!P.ws[0].active) return;
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
   if (col < 3) sync[col] = 0u;  // hand-off words of this factorisation's launches (see k_update_stream)
-  // "y_k is ready" words of the backward sweep (k_trsv_pipeline), then the tile counters of the band updates
+  // the tile counters of the band updates (behind one word per panel that older sweeps used)
   if (col < 2 * (npad / NB + 1)) flags[col] = 0u;
   if (col >= npad) return;
+  if (y_not_yet) reinterpret_cast<unsigned long long*>(y_not_yet)[col] = kNotYet;
   for (int row = n; row < ld; ++row) A[(long long)col * ld + row] = (row == col) ? 1.0 : 0.0;
   if (col < n) A[(long long)col * ld + npad] = P.b[6ll * P.wd[0].cam_base + col];
 }
@@ -904,15 +909,15 @@ __global__ __launch_bounds__(kTrsvThreads) void k_trsv_bwd(DevP P, const double*
 // The whole backward sweep in ONE launch: workgroup j (dispatched in the order the sweep needs them, last row
 // block first) owns row block j.  It applies z_j -= L(k,j)^T y_k for the row blocks k below it inside the envelope,
 // last one first, each as soon as y_k has been published, then forms y_j = Linv_j^T z_j and publishes it.  The
-// tile of the next step is already in registers while the workgroup waits, so a link of the chain is one flag
-// hand-off, a 1 KB read and two 128x128 matrix-vector products instead of a launch.
-// Hand-off without fences: y and the flags are written with write-through (agent-scope atomic) stores by one
-// workgroup, drained, then the flag is raised by one lane behind the workgroup's barrier; readers poll the flag and
-// read y with agent-scope loads only, behind a barrier of their own.  Every workgroup is resident at once (the
-// host uses this kernel for at most one workgroup per CU), and a workgroup only ever waits for lower-indexed ones.
+// tile of the next step is already in registers while the workgroup waits, so a link of the chain is one hand-off
+// of 1 KB and two 128x128 matrix-vector products instead of a launch.
+// Hand-off without flags or fences: y starts out as kNotYet in every word (k_pad_init); the owner stores its 128
+// values with write-through (agent-scope atomic) stores, and a reader's 128 lanes poll their own words with
+// agent-scope loads until each has seen a value -- one trip through memory per link instead of a drained store, a
+// flag and a second read behind it.  Every workgroup is resident at once (the host uses this kernel for at most one
+// workgroup per CU), and a workgroup only ever waits for lower-indexed ones.
 __global__ __launch_bounds__(kTrsvThreads) void k_trsv_pipeline(DevP P, const double* A, int ld, int nt, int npad,
-                                                                const int* first, const double* LinvT_all, double* y,
-                                                                unsigned* flags) {
+                                                                const int* first, const double* LinvT_all, double* y) {
   __shared__ double zj[NB];
   __shared__ double yk[NB];
   __shared__ double part[4][NB];
@@ -941,18 +946,19 @@ __global__ __launch_bounds__(kTrsvThreads) void k_trsv_pipeline(DevP P, const do
   if (klast > j) TRSV_TILE_LOAD(u, klast) else TRSV_LINV_LOAD(u);
   for (int k = klast; k > j; --k) {
     if (k - 1 > j) TRSV_TILE_LOAD(un, k - 1) else TRSV_LINV_LOAD(un);  // on its way while this step waits and computes
-    if (t == 0) {
-      int ok = 0;
+    if (t < NB) {
+      const unsigned long long* src = reinterpret_cast<const unsigned long long*>(y) + k * NB + t;
+      unsigned long long bits = kNotYet;
       for (int spin = 0; spin < (1 << 22); ++spin) {
-        if (__hip_atomic_load(flags + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 1; break; }
-        __builtin_amdgcn_s_sleep(2);
+        bits = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (bits != kNotYet) break;
+        __builtin_amdgcn_s_sleep(1);
       }
-      if (!ok) s_ok = 0;
+      if (bits == kNotYet) s_ok = 0;
+      yk[t] = __longlong_as_double((long long)bits);
     }
     __syncthreads();
     if (!s_ok) break;
-    if (t < NB) yk[t] = __hip_atomic_load(y + k * NB + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
     {
       double s0 = 0.0, s1 = 0.0;
 #pragma unroll
@@ -984,12 +990,11 @@ __global__ __launch_bounds__(kTrsvThreads) void k_trsv_pipeline(DevP P, const do
     part[h][r] = s0 + s1;
   }
   __syncthreads();
-  if (t < NB)
-    __hip_atomic_store(y + j * NB + t, (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (t == 0) __hip_atomic_store(flags + j, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (t < NB) {
+    double v = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+    if (v != v) v = __longlong_as_double(0x7ff8000000000000ll);  // never kNotYet (k_store_solution reports the NaN)
+    __hip_atomic_store(y + j * NB + t, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 __global__ void k_store_solution(DevP P, const double* y, int n) {
@@ -1040,7 +1045,14 @@ hipError_t big_solve_cholesky(const DevP& P, const BigWork& W, const int* h_firs
   const int* d_first = h_first ? W.first : nullptr;
   if (!P.dense_S)  // otherwise the elimination has written the blocks where they belong
     hipLaunchKernelGGL(k_unpack_lower, dim3((ncam * 36 + 255) / 256, ncam), dim3(256), 0, s, P, W.A, ld);
-  hipLaunchKernelGGL(k_pad_init, dim3((npad + 255) / 256), dim3(256), 0, s, P, W.A, n, npad, ld, W.sync, W.flags);
+  static const int max_resident = [] {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 0;
+  }();
+  const bool one_launch_sweep = nt <= max_resident;  // as one launch of nt workgroups that hand y_k to each other
+  hipLaunchKernelGGL(k_pad_init, dim3((npad + 255) / 256), dim3(256), 0, s, P, W.A, n, npad, ld, W.sync, W.flags,
+                     one_launch_sweep ? W.rhs : (double*)nullptr);
   // Two-level right-looking factorisation.  Panels of 128 columns are grouped in blocks of kOuter
   // panels.  Inside a block a freshly factored panel only updates the block's remaining panel columns
   // (narrow updates, K = 128); the rest of the trailing matrix is updated once per block with
@@ -1094,11 +1106,6 @@ hipError_t big_solve_cholesky(const DevP& P, const BigWork& W, const int* h_firs
       }
     }
   }
-  static const int max_resident = [] {
-    hipDeviceProp_t prop;
-    int dev = 0;
-    return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 0;
-  }();
   // Pipelined exchange of a sharded solve: the launches of panel p factor diagonal block p + 1 as well, so every
   // chunk that holds a tile column <= p + 1 is waited for and added before them.
   int fed = 0;
@@ -1143,10 +1150,10 @@ hipError_t big_solve_cholesky(const DevP& P, const BigWork& W, const int* h_firs
   if (feed_error != hipSuccess) return feed_error;
   double* z = W.rhs + npad;
   double* y = W.rhs;
-  if (nt <= max_resident) {
-    // the sweep as one launch of nt workgroups that hand y_k to each other (at most one per CU: all resident)
+  if (one_launch_sweep) {
+    // (at most one workgroup per CU: all resident)
     hipLaunchKernelGGL(k_trsv_pipeline, dim3(nt), dim3(kTrsvThreads), 0, s, P, (const double*)W.A, ld, nt, npad, d_first,
-                       (const double*)W.LinvT, y, W.flags);
+                       (const double*)W.LinvT, y);
   } else {
     hipLaunchKernelGGL(k_extract_z, dim3((npad + 255) / 256), dim3(256), 0, s, P, (const double*)W.A, npad, ld, z);
     hipLaunchKernelGGL(k_trsv_first, dim3(1), dim3(kTrsvThreads), 0, s, P, nt - 1, (const double*)W.LinvT, (const double*)z, y);
