@@ -47,7 +47,8 @@ def algorithmic_bytes(kernel, n_c, n_p, n_o, nnz_s):
     if kernel == "point_schur":
         return 168 * n_o + 168 * n_p + 336 * n_c + 8 * nnz_s
     if kernel == "backsub":
-        return 56 * n_o + 120 * n_p + 48 * n_c
+        # the pass also evaluates the cost at the candidate point: the back-substitution's and the cost pass's figures
+        return 56 * n_o + 120 * n_p + 48 * n_c + 24 * n_o + 56 * n_c + 24 * n_p
     raise KeyError(kernel)
 
 

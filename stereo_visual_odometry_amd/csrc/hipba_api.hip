@@ -1254,10 +1254,13 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
                                      sharded && direct && feed.n_chunks > 0 ? &feed : nullptr));
       }
     }
-    HIPBA_HIP(launch_backsub(P, lm, s));
+    // candidate poses first: the back-substitution then evaluates the candidate cost in the same pass over the
+    // observations (kept apart when the caller wants the residual evaluation timed on its own)
     if (!(small && !sharded)) HIPBA_HIP(launch_pose_update(P, s));
+    const bool cost_in_backsub = !timing && backsub_can_carry_cost(P);
+    HIPBA_HIP(launch_backsub(P, lm, cost_in_backsub, s));
     PHASE(2);
-    HIPBA_HIP(launch_cost(P, lm, 0, n_act_blk, 1, 0, true, s));
+    if (!cost_in_backsub) HIPBA_HIP(launch_cost(P, lm, 0, n_act_blk, 1, 0, true, s));
     PHASE(3);
     if (sharded) {
       HIPBA_HIP(launch_window_control(P, lm, kReduce, nullptr, 0, s));
@@ -1883,7 +1886,7 @@ int hipba_time_kernel(hipba_handle h, hipba_device_problem dp, const hipba_optio
           break;
         case HIPBA_KERNEL_CAMERA_BLOCKS: HIPBA_HIP(launch_camera_blocks(P, lm, 1, 0, s)); break;
         case HIPBA_KERNEL_POINT_SCHUR: HIPBA_HIP(launch_point_schur(P, lm, small_ncam, schur_parts, s)); break;
-        case HIPBA_KERNEL_BACKSUB: HIPBA_HIP(launch_backsub(P, lm, s)); break;
+        case HIPBA_KERNEL_BACKSUB: HIPBA_HIP(launch_backsub(P, lm, backsub_can_carry_cost(P), s)); break;
         case HIPBA_KERNEL_REDUCED_SOLVE: return solve_once();
         default: return fail(HIPBA_ERR_INVALID_ARGUMENT, "kernel %d cannot be timed on a resident problem", kernel);
       }

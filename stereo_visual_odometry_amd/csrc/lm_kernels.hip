@@ -956,10 +956,15 @@ __global__ __launch_bounds__(kBlock) void k_schur_gather(DevP P, LmParams lm) {
 //   model_cost_change = -sum m (r + m/2),  m = Jc step_c + Jp step_p   (Ceres'
 //   TrustRegionMinimizer::ComputeTrustRegionStep on the scaled Jacobian).
 // partial[b] = { sum m (r + m/2), |delta_p|^2, |x_p|^2 }
+// WITH_COST: the block's share of the cost at the candidate point as well, into the second bank of partial[] (what
+//   k_cost(which = 1) writes there, bit for bit: the same lanes hold the same observations and the sums take the same
+//   order).  The candidate poses must exist already (the solver launch or k_pose_update); the candidate landmark of an
+//   observation is formed in this very block.  Saves a pass over the observations and a launch per iteration.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_backsub(DevP P, LmParams lm) {
+template <bool WITH_COST>
+__global__ __launch_bounds__(kBlock) void k_backsub(DevP P, LmParams lm, double* cost_partial) {
   __shared__ double sh[kBlock * 3];
-  __shared__ double red[3 * 4];
+  __shared__ double red[5 * 4];
   const int b = blockIdx.x;
   const BlockDesc d = P.blocks[b];
   const int w = d.window;
@@ -972,17 +977,18 @@ __global__ __launch_bounds__(kBlock) void k_backsub(DevP P, LmParams lm) {
   const bool live = t < d.n_obs;
   double r[2] = {0, 0}, Jc[12], Jp[6];
   double mc[2] = {0, 0};  // Jc * step_c
-  int pp = -1;
+  int pp = -1, c = 0, s0 = 0;
+  double2 uv = make_double2(0.0, 0.0);
   bool has_c = false;
   if (live) {
     const long long o = d.obs_begin + t;
     pp = P.obs_dp[o];
-    const int c = P.obs_pose[o];
+    c = P.obs_pose[o];
     const int g = P.pose_gslot[c];
     has_c = g >= 0;
     const double* pose = P.poses[sel] + 7ll * c;
     const double* p = P.points[sel] + 3ll * pp;
-    const double2 uv = reinterpret_cast<const double2*>(P.obs_uv)[o];
+    uv = reinterpret_cast<const double2*>(P.obs_uv)[o];
     const bool pm = d.kind == 0;
     eval_obs<true>(wd.K, lm, pose, p, uv.x, uv.y, has_c ? P.scale_c + 6ll * g : nullptr,
                    pm ? P.scale_p + 3ll * pp : nullptr, r, Jc, Jp);
@@ -992,7 +998,10 @@ __global__ __launch_bounds__(kBlock) void k_backsub(DevP P, LmParams lm) {
       for (int i = 0; i < 6; ++i) { mc[0] -= Jc[i] * y[i]; mc[1] -= Jc[6 + i] * y[i]; }
     }
   }
-  double acc[3] = {0.0, 0.0, 0.0};
+  double acc[WITH_COST ? 5 : 3];
+#pragma unroll
+  for (int i = 0; i < (WITH_COST ? 5 : 3); ++i) acc[i] = 0.0;
+  double xn[3] = {0.0, 0.0, 0.0};  // the observation's landmark at the candidate point
   if (d.kind == 0) {
     if (live) {
       // W^T y_c = Jp^T (Jc y_c) = -Jp^T mc
@@ -1001,7 +1010,7 @@ __global__ __launch_bounds__(kBlock) void k_backsub(DevP P, LmParams lm) {
     }
     __syncthreads();
     if (live) {
-      const int s0 = (int)(P.pp_obs_start[pp] - d.obs_begin);
+      s0 = (int)(P.pp_obs_start[pp] - d.obs_begin);
       const int s1 = (int)(P.pp_obs_start[pp + 1] - d.obs_begin);
       double tt[3] = {P.gp[3ll * pp], P.gp[3ll * pp + 1], P.gp[3ll * pp + 2]};
       for (int j = s0; j < s1; ++j) {
@@ -1022,21 +1031,52 @@ __global__ __launch_bounds__(kBlock) void k_backsub(DevP P, LmParams lm) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
           const double dl = sp[i] * P.scale_p[3ll * pp + i];
-          const double xn = x[i] + dl;
-          xc[i] = xn;
-          const double df = x[i] - xn;
+          xn[i] = x[i] + dl;
+          xc[i] = xn[i];
+          const double df = x[i] - xn[i];
           acc[1] += df * df;
           acc[2] += x[i] * x[i];
         }
       }
     }
+    if (WITH_COST) {
+      // the landmark's first lane hands the candidate to the others through the words its sums came from
+      __syncthreads();
+      if (live && t == s0) { sh[3 * t] = xn[0]; sh[3 * t + 1] = xn[1]; sh[3 * t + 2] = xn[2]; }
+      __syncthreads();
+      if (live) { xn[0] = sh[3 * s0]; xn[1] = sh[3 * s0 + 1]; xn[2] = sh[3 * s0 + 2]; }
+    }
   } else if (live) {
     acc[0] = mc[0] * (r[0] + mc[0] / 2.0) + mc[1] * (r[1] + mc[1] / 2.0);
+    if (WITH_COST) {
+      const double* x = P.points[sel ^ 1] + 3ll * pp;  // a constant landmark: the same in both banks
+      xn[0] = x[0]; xn[1] = x[1]; xn[2] = x[2];
+    }
   }
-  block_sum<3>(acc, red);
+  if (WITH_COST && live) {
+    double pose[7];
+    const double* ps = P.poses[sel ^ 1] + 7ll * c;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) pose[i] = ps[i];
+    double rc[2];
+    residual_only(wd.K, pose, xn, uv.x, uv.y, rc);
+    const double s = rc[0] * rc[0] + rc[1] * rc[1];
+    double rho0 = s;
+    if (lm.loss == HIPBA_LOSS_HUBER) {
+      double f;
+      huber_correct(lm.loss_scale, s, &rho0, &f);
+    }
+    acc[3] = 0.5 * rho0;
+    acc[4] = isfinite(rho0) ? 0.0 : 1.0;
+  }
+  block_sum<(WITH_COST ? 5 : 3)>(acc, red);
   if (t == 0) {
     double* pr = P.partial + (long long)b * kPartialStride;
     pr[0] = acc[0]; pr[1] = acc[1]; pr[2] = acc[2];
+    if (WITH_COST) {
+      cost_partial[(long long)b * kPartialStride + 0] = acc[3];
+      cost_partial[(long long)b * kPartialStride + 1] = acc[4];
+    }
   }
 }
 
@@ -2225,10 +2265,18 @@ hipError_t launch_window_gradient(const DevP& P, const LmParams& lm, int mode, h
   return hipGetLastError();
 }
 
-hipError_t launch_backsub(const DevP& P, const LmParams& lm, hipStream_t s) {
+bool backsub_can_carry_cost(const DevP& P) { return P.n_long == 0; }
+
+hipError_t launch_backsub(const DevP& P, const LmParams& lm, bool with_cost, hipStream_t s) {
   const int nb = P.n_blk_pm + P.n_blk_vc;
   if (nb <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_backsub, dim3(nb), dim3(kBlock), 0, s, P, lm);
+  if (with_cost) {
+    // (the second bank of partial[]: where launch_cost(..., second_bank) puts the candidate cost)
+    double* bank2 = P.partial + ((long long)P.n_blk_pm + P.n_blk_vc + P.n_blk_cc) * kPartialStride;
+    hipLaunchKernelGGL(k_backsub<true>, dim3(nb), dim3(kBlock), 0, s, P, lm, bank2);
+  } else {
+    hipLaunchKernelGGL(k_backsub<false>, dim3(nb), dim3(kBlock), 0, s, P, lm, (double*)nullptr);
+  }
   if (P.n_long > 0) hipLaunchKernelGGL(k_long_point<2>, dim3(P.n_long), dim3(kBlock), 0, s, P, lm);
   return hipGetLastError();
 }
