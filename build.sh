@@ -8,14 +8,14 @@ mkdir -p "$OUT" build
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -munsafe-fp-atomics -Wall -Wno-unused-function -Iinclude"
 pids=()
-for f in lm_kernels dense_solver hipba_api rccl_comm; do
+for f in lm_kernels dense_solver hipba_api rccl_comm stereo_kernels; do
   if [ ! -f build/$f.o ] || [ $SRC/$f.hip -nt build/$f.o ] || [ -n "$(find $SRC include -name '*.h*' -newer build/$f.o | head -1)" ]; then
     $HIPCC $FLAGS -c $SRC/$f.hip -o build/$f.o &
     pids+=($!)
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT/libhipba.so build/lm_kernels.o build/dense_solver.o build/hipba_api.o build/rccl_comm.o -ldl
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT/libhipba.so build/lm_kernels.o build/dense_solver.o build/hipba_api.o build/rccl_comm.o build/stereo_kernels.o -ldl
 echo "built $OUT/libhipba.so"
 # C++ host adapter demo: the ROS-free ba_test harness (plain g++, links the C ABI only)
 g++ -O2 -std=c++17 -Wall -Iinclude -I$SRC/host -o $OUT/ba_test $SRC/host/ba_test_cli.cpp -L$OUT -lhipba -Wl,-rpath,'$ORIGIN'

@@ -292,6 +292,36 @@ int hipba_download(hipba_handle h, hipba_device_problem dp, int32_t window, doub
                    double* points);
 int hipba_free_problem(hipba_handle h, hipba_device_problem dp);
 
+/* ---- the steps either side of bundle adjustment in the per-frame pipeline ------------------- */
+/*
+ * Linear triangulation of stereo matches, what Triangulator::triangulate does for every keyframe
+ * (src/solve/triangulator.cpp:48-61): cv::triangulatePoints(P_left, P_right, left, right) -- per match the null
+ * vector of the 4x4 system x P(2,:) - P(0,:), y P(2,:) - P(1,:) of both cameras --, then
+ * cv::convertPointsFromHomogeneous (the homogeneous point rounded to float as OpenCV stores it, divided by w in
+ * float; w == 0 leaves it undivided), then frame_prev_->pose_ * point.  P_left / P_right: the 3x4 projection
+ * matrices, row-major (sensor/camera.hpp: Camera::P_); left_uv / right_uv: n pixel pairs as cv::Point2f lays them
+ * out; pose: qx qy qz qw tx ty tz of the frame (Sophus::SE3d::data()), or NULL to stay in the camera frame;
+ * points: [3 n] doubles.  Points at negative depth or infinity come out as they are, as in the reference.
+ * hipba_triangulate_stereo takes HOST arrays and returns when points is filled; the _device form takes DEVICE
+ * pointers for every argument, allocates nothing, queues its one kernel on the handle's stream and returns.
+ */
+int hipba_triangulate_stereo(hipba_handle h, const double P_left[12], const double P_right[12], int64_t n,
+                             const float* left_uv, const float* right_uv, const double* pose, double* points);
+int hipba_triangulate_stereo_device(hipba_handle h, const double* d_P_left, const double* d_P_right, int64_t n,
+                                    const float* d_left_uv, const float* d_right_uv, const double* d_pose,
+                                    double* d_points);
+/*
+ * Pose-only refinement on 3D-2D matches: the minimisation of the reprojection error over one camera pose that ends
+ * cv::solvePnPRansac (src/solve/estimator.cpp:28-29), as a bundle adjustment with every landmark constant -- same
+ * residual, same SE3 parameterisation and the same Levenberg-Marquardt as hipba_solve.  The RANSAC hypothesis
+ * search stays with the caller: `use` is its inlier mask ([n] or NULL = all).  points: [3 n] world coordinates,
+ * uv: [2 n] pixels, pose: in = the hypothesis to refine, out = the refined camera-to-world pose (what
+ * estimator.cpp:58-59 calls curr_pose).  HIPBA_ERR_INVALID_ARGUMENT with fewer than 3 matches in use.
+ */
+int hipba_refine_pose(hipba_handle h, double fx, double fy, double cx, double cy, int32_t camera_model, int64_t n,
+                      const double* points, const double* uv, const uint8_t* use, double pose[7],
+                      const hipba_options* options, hipba_summary* summary);
+
 /* ---- native RCCL communicator for sharded solves ------------------------------------------ */
 /*
  * A hipba_comm whose all-reduce is ncclAllReduce (RCCL over xGMI) queued on the engine's stream: for C / C++

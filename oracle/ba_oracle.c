@@ -1068,3 +1068,89 @@ int oracle_lm_step(const oracle_problem* P, const oracle_options* O, double radi
   prog_free(&g);
   return rc;
 }
+
+/* ---- stereo triangulation (src/solve/triangulator.cpp:48-61) ---------------------------------- */
+/* right singular vector of the smallest singular value of the 4x4 matrix whose COLUMNS are a[0..3]:
+ * Hestenes' one-sided Jacobi, the method of cv::SVD for small matrices */
+static void smallest_right_singular_vector(double a[4][4], double out[4]) {
+  double v[4][4];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) v[i][j] = i == j ? 1.0 : 0.0;
+  const double eps = 2.0 * 2.220446049250313e-16;
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    int changed = 0;
+    for (int i = 0; i < 3; ++i) {
+      for (int j = i + 1; j < 4; ++j) {
+        double aa = 0.0, bb = 0.0, p = 0.0;
+        for (int k = 0; k < 4; ++k) {
+          aa += a[i][k] * a[i][k];
+          bb += a[j][k] * a[j][k];
+          p += a[i][k] * a[j][k];
+        }
+        if (fabs(p) <= eps * sqrt(aa * bb)) continue;
+        p *= 2.0;
+        const double beta = aa - bb, gamma = hypot(p, beta);
+        double c, s;
+        if (beta < 0.0) {
+          const double delta = (gamma - beta) * 0.5;
+          s = sqrt(delta / gamma);
+          c = p / (gamma * s * 2.0);
+        } else {
+          c = sqrt((gamma + beta) / (gamma * 2.0));
+          s = p / (gamma * c * 2.0);
+        }
+        for (int k = 0; k < 4; ++k) {
+          const double x = a[i][k], y = a[j][k];
+          a[i][k] = c * x + s * y;
+          a[j][k] = c * y - s * x;
+          const double vx = v[i][k], vy = v[j][k];
+          v[i][k] = c * vx + s * vy;
+          v[j][k] = c * vy - s * vx;
+        }
+        changed = 1;
+      }
+    }
+    if (!changed) break;
+  }
+  int best = 0;
+  double best_norm = 0.0;
+  for (int i = 0; i < 4; ++i) {
+    double nn = 0.0;
+    for (int k = 0; k < 4; ++k) nn += a[i][k] * a[i][k];
+    if (i == 0 || nn < best_norm) { best = i; best_norm = nn; }
+  }
+  for (int k = 0; k < 4; ++k) out[k] = v[best][k];
+}
+
+void oracle_triangulate_stereo(const double* Pl, const double* Pr, int64_t n, const float* luv,
+                               const float* ruv, const double* pose7, double* out) {
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) {
+    const double xl = luv[2 * i], yl = luv[2 * i + 1], xr = ruv[2 * i], yr = ruv[2 * i + 1];
+    double a[4][4];
+    for (int k = 0; k < 4; ++k) {  /* cv::triangulatePoints: rows x P(2,:) - P(0,:), y P(2,:) - P(1,:) per camera */
+      a[k][0] = xl * Pl[8 + k] - Pl[k];
+      a[k][1] = yl * Pl[8 + k] - Pl[4 + k];
+      a[k][2] = xr * Pr[8 + k] - Pr[k];
+      a[k][3] = yr * Pr[8 + k] - Pr[4 + k];
+    }
+    double h[4];
+    smallest_right_singular_vector(a, h);
+    /* points_4d is CV_32F (triangulator.cpp:43-48 passes Point2f); convertPointsFromHomogeneous divides in float */
+    const float X = (float)h[0], Y = (float)h[1], Z = (float)h[2], W = (float)h[3];
+    const float scale = W != 0.f ? 1.f / W : 1.f;
+    double p[3] = {(double)(X * scale), (double)(Y * scale), (double)(Z * scale)};
+    if (pose7) {  /* triangulator.cpp:61: frame_prev_->pose_ * landmark */
+      double R[9];
+      const double qx = pose7[0], qy = pose7[1], qz = pose7[2], qw = pose7[3];
+      R[0] = 1 - 2 * (qy * qy + qz * qz); R[1] = 2 * (qx * qy - qz * qw);     R[2] = 2 * (qx * qz + qy * qw);
+      R[3] = 2 * (qx * qy + qz * qw);     R[4] = 1 - 2 * (qx * qx + qz * qz); R[5] = 2 * (qy * qz - qx * qw);
+      R[6] = 2 * (qx * qz - qy * qw);     R[7] = 2 * (qy * qz + qx * qw);     R[8] = 1 - 2 * (qx * qx + qy * qy);
+      const double x = p[0], y = p[1], z = p[2];
+      p[0] = R[0] * x + R[1] * y + R[2] * z + pose7[4];
+      p[1] = R[3] * x + R[4] * y + R[5] * z + pose7[5];
+      p[2] = R[6] * x + R[7] * y + R[8] * z + pose7[6];
+    }
+    out[3 * i] = p[0]; out[3 * i + 1] = p[1]; out[3 * i + 2] = p[2];
+  }
+}

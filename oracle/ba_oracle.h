@@ -148,6 +148,19 @@ int oracle_solve(oracle_problem* p, const oracle_options* o, oracle_summary* s,
 int oracle_lm_step(const oracle_problem* p, const oracle_options* o, double radius,
                    double* step_pose, double* step_point, double* model_cost_change);
 
+/*
+ * Linear triangulation of stereo matches as Triangulator::triangulate does it
+ * (src/solve/triangulator.cpp:48-61): cv::triangulatePoints, cv::convertPointsFromHomogeneous,
+ * then frame pose * point.  OpenCV is not in this image (PARITY UNPINNED here as well): this restates
+ * its published method -- per match the 4x4 system x P(2,:) - P(0,:), y P(2,:) - P(1,:) of both
+ * cameras, the right singular vector of the smallest singular value by one-sided Jacobi rotations
+ * (what cv::SVD runs on a small matrix), the homogeneous point stored as float like the float
+ * pixels it came from, and the division by w in float (w == 0: undivided).
+ * Pl, Pr: 3x4 row-major; luv, ruv: [2n] floats; pose7: qx qy qz qw tx ty tz or NULL; out: [3n].
+ */
+void oracle_triangulate_stereo(const double* Pl, const double* Pr, int64_t n, const float* luv,
+                               const float* ruv, const double* pose7, double* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -97,6 +97,8 @@ def lib():
         _lib.oracle_solve.restype = C.c_int
         _lib.oracle_lm_step.argtypes = [C.POINTER(CProblem), C.POINTER(COptions), C.c_double, _dp, _dp, _dp]
         _lib.oracle_lm_step.restype = C.c_int
+        _lib.oracle_triangulate_stereo.argtypes = [_dp, _dp, C.c_int64, C.POINTER(C.c_float), C.POINTER(C.c_float), _dp, _dp]
+        _lib.oracle_triangulate_stereo.restype = None
     return _lib
 
 
@@ -231,3 +233,18 @@ def lm_step(prob, options, radius):
     rc = lib().oracle_lm_step(C.byref(cp), C.byref(options), float(radius), _d(sp), _d(sq),
                               C.cast(C.byref(mc), _dp))
     return rc, sp, sq, mc.value
+
+
+def triangulate_stereo(P_left, P_right, left_uv, right_uv, pose=None):
+    """oracle_triangulate_stereo: [n, 3] points (world frame when `pose` -- qx qy qz qw tx ty tz -- is given)."""
+    pl = np.ascontiguousarray(P_left, dtype=np.float64).reshape(12)
+    pr = np.ascontiguousarray(P_right, dtype=np.float64).reshape(12)
+    l = np.ascontiguousarray(left_uv, dtype=np.float32).reshape(-1, 2)
+    r = np.ascontiguousarray(right_uv, dtype=np.float32).reshape(-1, 2)
+    assert l.shape == r.shape
+    out = np.zeros((l.shape[0], 3))
+    ps = None if pose is None else np.ascontiguousarray(pose, dtype=np.float64).reshape(7)
+    fp = C.POINTER(C.c_float)
+    lib().oracle_triangulate_stereo(_d(pl), _d(pr), l.shape[0], l.ctypes.data_as(fp), r.ctypes.data_as(fp),
+                                  None if ps is None else _d(ps), _d(out))
+    return out

@@ -1796,6 +1796,88 @@ int hipba_evaluate_device(hipba_handle h, int32_t n_poses, const double* d_poses
   });
 }
 
+int hipba_triangulate_stereo_device(hipba_handle h, const double* d_P_left, const double* d_P_right, int64_t n,
+                                    const float* d_left_uv, const float* d_right_uv, const double* d_pose,
+                                    double* d_points) {
+  return guarded([&]() -> int {
+    if (!h) return fail(HIPBA_ERR_INVALID_ARGUMENT, "null handle");
+    if (n < 0) return fail(HIPBA_ERR_INVALID_ARGUMENT, "negative size");
+    if (n == 0) return HIPBA_OK;
+    if (!d_P_left || !d_P_right || !d_left_uv || !d_right_uv || !d_points)
+      return fail(HIPBA_ERR_INVALID_ARGUMENT, "null input array");
+    HIPBA_HIP(hipSetDevice(h->device));
+    HIPBA_HIP(launch_triangulate_stereo(d_P_left, d_P_right, n, d_left_uv, d_right_uv, d_pose, d_points, h->stream));
+    return HIPBA_OK;
+  });
+}
+
+int hipba_triangulate_stereo(hipba_handle h, const double P_left[12], const double P_right[12], int64_t n,
+                             const float* left_uv, const float* right_uv, const double* pose, double* points) {
+  return guarded([&]() -> int {
+    if (!h) return fail(HIPBA_ERR_INVALID_ARGUMENT, "null handle");
+    if (n < 0) return fail(HIPBA_ERR_INVALID_ARGUMENT, "negative size");
+    if (n == 0) return HIPBA_OK;
+    if (!P_left || !P_right || !left_uv || !right_uv || !points) return fail(HIPBA_ERR_INVALID_ARGUMENT, "null input array");
+    HIPBA_HIP(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    // one staging block, one copy each way: [P_left 12][P_right 12][pose 7 + 1][left 2n floats][right 2n floats] -> [3n]
+    const size_t head = sizeof(double) * 32, uv_bytes = sizeof(float) * 2 * (size_t)n, out_bytes = sizeof(double) * 3 * (size_t)n;
+    const size_t in_bytes = align_up(head + 2 * uv_bytes, 256);
+    int rc = ensure_staging(h, std::max(in_bytes, out_bytes));
+    if (rc) return rc;
+    rc = ensure_arena(h, in_bytes + out_bytes);
+    if (rc) return rc;
+    char* st = static_cast<char*>(h->staging);
+    double* hd = reinterpret_cast<double*>(st);
+    for (int i = 0; i < 12; ++i) { hd[i] = P_left[i]; hd[12 + i] = P_right[i]; }
+    for (int i = 0; i < 7; ++i) hd[24 + i] = pose ? pose[i] : 0.0;
+    hd[31] = 0.0;
+    memcpy(st + head, left_uv, uv_bytes);
+    memcpy(st + head + uv_bytes, right_uv, uv_bytes);
+    char* dv = static_cast<char*>(h->arena);
+    HIPBA_HIP(hipMemcpyAsync(dv, st, head + 2 * uv_bytes, hipMemcpyHostToDevice, s));
+    const double* d_head = reinterpret_cast<const double*>(dv);
+    double* d_out = reinterpret_cast<double*>(dv + in_bytes);
+    HIPBA_HIP(launch_triangulate_stereo(d_head, d_head + 12, n, reinterpret_cast<const float*>(dv + head),
+                                        reinterpret_cast<const float*>(dv + head + uv_bytes), pose ? d_head + 24 : nullptr,
+                                        d_out, s));
+    HIPBA_HIP(hipMemcpyAsync(st, d_out, out_bytes, hipMemcpyDeviceToHost, s));
+    HIPBA_HIP(hipStreamSynchronize(s));
+    memcpy(points, st, out_bytes);
+    return HIPBA_OK;
+  });
+}
+
+int hipba_refine_pose(hipba_handle h, double fx, double fy, double cx, double cy, int32_t camera_model, int64_t n,
+                      const double* points, const double* uv, const uint8_t* use, double pose[7],
+                      const hipba_options* options, hipba_summary* summary) {
+  return guarded([&]() -> int {
+    if (!h || !pose) return fail(HIPBA_ERR_INVALID_ARGUMENT, "null argument");
+    if (n < 0 || (n > 0 && (!points || !uv))) return fail(HIPBA_ERR_INVALID_ARGUMENT, "null input array");
+    // one variable pose, the matches in use as constant landmarks with one observation each
+    std::vector<double> pts, px;
+    pts.reserve(3 * (size_t)n); px.reserve(2 * (size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+      if (use && !use[i]) continue;
+      pts.insert(pts.end(), points + 3 * i, points + 3 * i + 3);
+      px.insert(px.end(), uv + 2 * i, uv + 2 * i + 2);
+    }
+    const size_t m = px.size() / 2;
+    if (m < 3) return fail(HIPBA_ERR_INVALID_ARGUMENT, "pose refinement needs at least 3 matches in use (got %zu)", m);
+    if (m > (size_t)INT32_MAX) return fail(HIPBA_ERR_INVALID_ARGUMENT, "too many matches");
+    std::vector<uint8_t> point_const(m, 1);
+    std::vector<int32_t> obs_pose(m, 0), obs_point(m);
+    for (size_t i = 0; i < m; ++i) obs_point[i] = (int32_t)i;
+    hipba_problem p{};
+    p.n_poses = 1; p.poses = pose; p.pose_const = nullptr;
+    p.n_points = (int32_t)m; p.points = pts.data(); p.point_const = point_const.data();
+    p.n_obs = (int64_t)m; p.obs_pose = obs_pose.data(); p.obs_point = obs_point.data(); p.obs_uv = px.data();
+    p.fx = fx; p.fy = fy; p.cx = cx; p.cy = cy; p.camera_model = camera_model;
+    hipba_summary local;
+    return hipba_solve(h, &p, options, summary ? summary : &local);
+  });
+}
+
 int hipba_reduced_solve_flops(hipba_device_problem dp, double* flops_dense, double* flops_envelope) {
   return guarded([&]() -> int {
     if (!dp) return fail(HIPBA_ERR_INVALID_ARGUMENT, "null argument");

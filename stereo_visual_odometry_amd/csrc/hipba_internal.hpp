@@ -35,6 +35,10 @@ hipError_t launch_residual_jacobian(const CameraK& K, const LmParams& lm, int ap
                                     const int* obs_point, const double* obs_uv, double* res, double* jc, double* jp,
                                     double* cost_part, double* cost_out, hipStream_t s);
 
+// ---- stereo triangulation (stereo_kernels.hip): every pointer is device memory; pose may be null ----
+hipError_t launch_triangulate_stereo(const double* d_pl, const double* d_pr, long long n, const float* d_left,
+                                     const float* d_right, const double* d_pose, double* d_out, hipStream_t s);
+
 // ---- reduced-system solvers for one large window (dense_solver.hip) ----------------------------
 struct BigWork {
   int n = 0;           // 6 * ncam

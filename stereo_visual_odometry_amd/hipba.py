@@ -97,6 +97,7 @@ EXPORTED_SYMBOLS = [
     "hipba_solve", "hipba_solve_batched", "hipba_evaluate", "hipba_evaluate_device", "hipba_upload", "hipba_upload_shard", "hipba_pose_order", "hipba_reset", "hipba_solve_device",
     "hipba_solve_device_sharded", "hipba_download", "hipba_free_problem", "hipba_time_kernel", "hipba_reduced_solve_flops",
     "hipba_rccl_get_unique_id", "hipba_rccl_comm_create", "hipba_rccl_comm_stats", "hipba_rccl_comm_destroy",
+    "hipba_triangulate_stereo", "hipba_triangulate_stereo_device", "hipba_refine_pose",
 ]
 
 
@@ -173,6 +174,12 @@ def load_library(path=None):
     lib.hipba_solve_batched.argtypes = [C.c_void_p, C.c_int32, C.POINTER(CProblem), C.POINTER(COptions),
                                         C.POINTER(CSummary)]
     lib.hipba_evaluate.argtypes = [C.c_void_p, C.POINTER(CProblem), C.POINTER(COptions), C.c_int, _dp, _dp, _dp, _dp]
+    fp = C.POINTER(C.c_float)
+    lib.hipba_triangulate_stereo.argtypes = [C.c_void_p, _dp, _dp, C.c_int64, fp, fp, _dp, _dp]
+    lib.hipba_triangulate_stereo_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                                    C.c_void_p, C.c_void_p]
+    lib.hipba_refine_pose.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int64,
+                                      _dp, _dp, _bp, _dp, C.POINTER(COptions), C.POINTER(CSummary)]
     lib.hipba_evaluate_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double,
                                           C.c_double, C.c_int32, C.POINTER(COptions), C.c_int, C.c_void_p, C.c_void_p,
@@ -412,6 +419,44 @@ class Solver:
                                                d_obs_point, d_obs_uv, K[0], K[1], K[2], K[3], camera_model,
                                                C.byref(o), int(bool(apply_loss)), d_cost, d_residuals, d_jac_pose,
                                                d_jac_point))
+
+    def triangulate_stereo(self, P_left, P_right, left_uv, right_uv, pose=None):
+        """hipba_triangulate_stereo (Triangulator::triangulate, triangulator.cpp:48-61): [n, 3] points from n stereo
+        matches (float pixel pairs), in the world frame when the frame's pose (qx qy qz qw tx ty tz) is given."""
+        pl = np.ascontiguousarray(P_left, dtype=np.float64).reshape(12)
+        pr = np.ascontiguousarray(P_right, dtype=np.float64).reshape(12)
+        l = np.ascontiguousarray(left_uv, dtype=np.float32).reshape(-1, 2)
+        r = np.ascontiguousarray(right_uv, dtype=np.float32).reshape(-1, 2)
+        if l.shape != r.shape:
+            raise ValueError("left_uv and right_uv differ in length")
+        ps = None if pose is None else np.ascontiguousarray(pose, dtype=np.float64).reshape(7)
+        out = np.zeros((l.shape[0], 3))
+        fp = C.POINTER(C.c_float)
+        _check(self._lib.hipba_triangulate_stereo(self._h, pl.ctypes.data_as(_dp), pr.ctypes.data_as(_dp), l.shape[0],
+                                                  l.ctypes.data_as(fp), r.ctypes.data_as(fp),
+                                                  None if ps is None else ps.ctypes.data_as(_dp), out.ctypes.data_as(_dp)))
+        return out
+
+    def triangulate_stereo_device(self, d_P_left, d_P_right, n, d_left_uv, d_right_uv, d_pose, d_points):
+        """hipba_triangulate_stereo_device: device addresses (ints), queued on this handle's stream, nothing allocated."""
+        _check(self._lib.hipba_triangulate_stereo_device(self._h, d_P_left, d_P_right, n, d_left_uv, d_right_uv, d_pose,
+                                                         d_points))
+
+    def refine_pose(self, K, points, uv, pose, use=None, camera_model=CAMERA_Z_FORWARD, options=None):
+        """hipba_refine_pose (the refinement that ends cv::solvePnPRansac, estimator.cpp:28-29): (refined pose, summary)."""
+        o = options if options is not None else default_options()
+        pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+        px = np.ascontiguousarray(uv, dtype=np.float64).reshape(-1, 2)
+        if pts.shape[0] != px.shape[0]:
+            raise ValueError("points and uv differ in length")
+        ps = np.ascontiguousarray(pose, dtype=np.float64).reshape(7).copy()
+        mask = None if use is None else np.ascontiguousarray(use, dtype=np.uint8)
+        summ = CSummary()
+        _check(self._lib.hipba_refine_pose(self._h, K[0], K[1], K[2], K[3], camera_model, pts.shape[0],
+                                           pts.ctypes.data_as(_dp), px.ctypes.data_as(_dp),
+                                           None if mask is None else mask.ctypes.data_as(_bp), ps.ctypes.data_as(_dp),
+                                           C.byref(o), C.byref(summ)))
+        return ps, _summary_dict(summ)
 
     def upload(self, problems):
         if isinstance(problems, Problem):

@@ -210,3 +210,55 @@ def shard_by_point(prob, rank, world_size):
     point_const = None if prob.point_const is None else prob.point_const[lo:hi]
     return hipba.Problem(prob.poses, prob.points[lo:hi], prob.obs_pose[sel], prob.obs_point[sel] - lo,
                          prob.obs_uv[sel], prob.K, prob.camera_model, prob.pose_const, point_const), (lo, hi)
+
+
+# KITTI odometry's rectified stereo pair (calib.txt P0 / P1 of sequence 00): same intrinsics, 0.54 m baseline
+STEREO_BASELINE = 0.537165718864
+P_LEFT = np.array([[FX, 0.0, CX, 0.0], [0.0, FY, CY, 0.0], [0.0, 0.0, 1.0, 0.0]])
+P_RIGHT = np.array([[FX, 0.0, CX, -FX * STEREO_BASELINE], [0.0, FY, CY, 0.0], [0.0, 0.0, 1.0, 0.0]])
+
+
+def stereo_matches(seed, n, pixel_sigma=0.3, depth_lo=4.0, depth_hi=60.0):
+    """n stereo matches of a KITTI-like rectified pair, as the frontend's matcher hands them to the triangulator:
+    float pixel pairs of points uniform in the left camera's frustum, with matching noise in both images.
+    Returns (left_uv, right_uv, points in the left camera's frame, a frame pose)."""
+    rng = np.random.default_rng(seed)
+    z = rng.uniform(depth_lo, depth_hi, n)
+    u = rng.uniform(0.0, 1241.0, n)
+    v = rng.uniform(0.0, 376.0, n)
+    pts = np.stack([(u - CX) / FX * z, (v - CY) / FY * z, z], axis=1)
+    h = np.c_[pts, np.ones(n)]
+    def project(P):
+        q = h @ P.T
+        return q[:, :2] / q[:, 2:]
+    left = (project(P_LEFT) + rng.normal(0.0, pixel_sigma, (n, 2))).astype(np.float32)
+    right = (project(P_RIGHT) + rng.normal(0.0, pixel_sigma, (n, 2))).astype(np.float32)
+    pose = np.zeros(7)
+    pose[:4] = _quat_from_rotvec(rng.normal(0.0, 0.3, (1, 3)))[0]
+    pose[4:] = rng.normal(0.0, 20.0, 3)
+    return left, right, pts, pose
+
+
+def pnp_case(seed, n=400, pixel_sigma=0.3, outlier_fraction=0.0, sigma_t=0.2, sigma_w=0.02):
+    """3D-2D matches of one frame, as the estimator sees them: landmarks in the world frame, their pixels in a camera
+    at a known pose, a starting pose nearby (what a RANSAC hypothesis is to the refinement), optionally gross outliers
+    with an inlier mask.  Returns (points, uv, start pose, true pose, mask)."""
+    rng = np.random.default_rng(seed)
+    true = np.zeros((1, 7))
+    true[0, :4] = _quat_from_rotvec(rng.normal(0.0, 0.2, (1, 3)))[0]
+    true[0, 4:] = rng.normal(0.0, 5.0, 3)
+    z = rng.uniform(4.0, 60.0, n)
+    u = rng.uniform(0.0, 1241.0, n)
+    v = rng.uniform(0.0, 376.0, n)
+    pc = np.stack([(u - CX) / FX * z, (v - CY) / FY * z, z], axis=1)
+    pts = _rotate(np.repeat(true[:, :4], n, axis=0), pc) + true[0, 4:]
+    uv = np.stack([u, v], axis=1) + rng.normal(0.0, pixel_sigma, (n, 2))
+    uv = uv.astype(np.float32).astype(np.float64)
+    mask = np.ones(n, dtype=np.uint8)
+    n_out = int(outlier_fraction * n)
+    if n_out:
+        bad = rng.choice(n, n_out, replace=False)
+        uv[bad] = np.stack([rng.uniform(0.0, 1241.0, n_out), rng.uniform(0.0, 376.0, n_out)], axis=1)
+        mask[bad] = 0
+    start = _perturb_poses(rng, true, sigma_t, sigma_w)[0]
+    return pts, uv, start, true[0], mask
