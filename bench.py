@@ -252,6 +252,61 @@ def secondary_measurements(solver, with_cpu, threads):
                                         "first %d of the same 1024 windows, one after another" % n_cpu}
     out["batched_small_windows"] = bw
     out["concurrent_sequences"] = concurrent_sequences(solver.device)
+    out["frontend_steps"] = frontend_steps(solver, with_cpu, threads)
+    return out
+
+
+def frontend_steps(solver, with_cpu, threads):
+    """The data-parallel steps either side of the bundle adjustment in the per-frame pipeline: stereo triangulation
+    (matches resident in HBM, one kernel) and the pose refinement that ends PnP (host call, upload included)."""
+    import torch
+    from stereo_visual_odometry_amd import hipba, scenes
+    out = {}
+    n = 1 << 20
+    left, right, _, pose = scenes.stereo_matches(4000, n)
+    dev = torch.device("cuda", solver.device)
+    d = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in
+         (scenes.P_LEFT.reshape(12), scenes.P_RIGHT.reshape(12), left, right, pose)]
+    d_out = torch.empty((n, 3), dtype=torch.float64, device=dev)
+    stream = torch.cuda.ExternalStream(int(solver.stream), device=dev)
+    torch.cuda.synchronize(dev)
+    call = lambda: solver.triangulate_stereo_device(d[0].data_ptr(), d[1].data_ptr(), n, d[2].data_ptr(), d[3].data_ptr(),
+                                                    d[4].data_ptr(), d_out.data_ptr())
+    call()
+    stream.synchronize()
+    reps = 20
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        call()
+    stream.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    algorithmic = 40.0 * n  # two float pixel pairs in, three doubles out
+    tri = {"matches": n, "matches_per_s": n / dt, "ms": 1e3 * dt,
+           "workload": "2^20 stereo matches of a KITTI-like rectified pair, resident in HBM, lifted to the world frame",
+           "roofline": {"bound": "hbm", "achieved": algorithmic / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": algorithmic / dt / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "note": "40 B per match; the kernel is bound by the 4x4 Jacobi SVD's fp64 arithmetic, not by HBM"}}
+    if with_cpu:
+        from oracle import oracle
+        oracle.triangulate_stereo(scenes.P_LEFT, scenes.P_RIGHT, left[:1000], right[:1000], pose)
+        t0 = time.perf_counter()
+        oracle.triangulate_stereo(scenes.P_LEFT, scenes.P_RIGHT, left, right, pose)
+        dtc = time.perf_counter() - t0
+        tri["cpu_baseline"] = {"value": n / dtc, "unit": "matches/s", "cores": threads, "kind": "port",
+                               "sample": "the oracle's restatement of cv::triangulatePoints on the same matches (OpenMP)"}
+    out["stereo_triangulation"] = tri
+    pts, uv, start, _, mask = scenes.pnp_case(4001, n=800, outlier_fraction=0.2)
+    opts = hipba.default_options(max_num_iterations=50)
+    solver.refine_pose(scenes.KITTI_K, pts, uv, start, use=mask, options=opts)
+    t, its = [], []
+    for k in range(8):
+        pts, uv, start, _, mask = scenes.pnp_case(4002 + k, n=800, outlier_fraction=0.2)
+        t0 = time.perf_counter()
+        _, s = solver.refine_pose(scenes.KITTI_K, pts, uv, start, use=mask, options=opts)
+        t.append(time.perf_counter() - t0)
+        its.append(s["num_iterations"] - 1)
+    out["pose_refinement"] = {"ms_per_call": 1e3 * float(np.mean(t)), "lm_iterations_per_call": float(np.mean(its)),
+                              "workload": "800 3D-2D matches, 640 in use, host arrays in, refined pose out; mean of 8"}
     return out
 
 
