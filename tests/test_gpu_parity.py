@@ -477,6 +477,23 @@ def test_sharded_tile_exchange_in_one_piece_and_pipelined(monkeypatch):
     assert all(count < tile_words for count, _, on_engine in traces[None] if on_engine)
 
 
+def test_sharded_tile_exchange_three_ranks():
+    """Three ranks (an odd count: uneven landmark blocks, envelopes merged over more than two contributions)."""
+    prob = scenes.bal_scale(seed=38, grid=(60, 4), n_points=180000, depth_lo=5.0, depth_hi=15.0)[0]
+    opts = lambda: hipba.default_options(max_num_iterations=4)
+    ref = prob.copy()
+    sv = hipba.Solver(0)
+    s_ref = sv.solve(ref, opts())
+    sv.close()
+    trace = []
+    for s, poses, pts, lo, hi in run_threaded_ranks(prob, opts, world=3, trace=trace):
+        assert s["termination_type"] == s_ref["termination_type"] and s["num_iterations"] == s_ref["num_iterations"]
+        assert abs(s["final_cost"] - s_ref["final_cost"]) <= 1e-9 * s_ref["final_cost"]
+        assert np.abs(poses - ref.poses).max() <= 1e-8
+        assert np.abs(pts - ref.points[lo:hi]).max() <= 1e-7
+    assert any(not on_engine for _, _, on_engine in trace)  # the tiles travelled in pieces beside the factorisation
+
+
 def test_pipelined_exchange_with_the_native_rccl_communicator_single_rank(monkeypatch):
     """The chunked exchange through the library's own RCCL communicator, as far as one GPU allows: with
     HIPBA_SHARD_SINGLE_RANK a communicator of one rank goes through the whole sharded path (every all-reduce is the
