@@ -1017,14 +1017,18 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   hipError_t e = hipMemcpyAsync(R->arena, h->staging, upload_bytes, hipMemcpyHostToDevice, s);
   if (e == hipSuccess) e = hipMemcpyAsync(P.poses[1], P.poses[0], poses.size() * 8, hipMemcpyDeviceToDevice, s);
   if (e == hipSuccess) e = hipMemcpyAsync(P.points[1], P.points[0], points.size() * 8, hipMemcpyDeviceToDevice, s);
-  if (e == hipSuccess) e = hipMemcpyAsync(R->poses0, P.poses[0], poses.size() * 8, hipMemcpyDeviceToDevice, s);
-  if (e == hipSuccess) e = hipMemcpyAsync(R->points0, P.points[0], points.size() * 8, hipMemcpyDeviceToDevice, s);
+  if (!use_handle_arena) {  // (a one-shot solve is never reset)
+    if (e == hipSuccess) e = hipMemcpyAsync(R->poses0, P.poses[0], poses.size() * 8, hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(R->points0, P.points[0], points.size() * 8, hipMemcpyDeviceToDevice, s);
+  }
   if (e == hipSuccess) e = hipMemsetAsync(P.ws, 0, sizeof(WinState) * nw, s);
   if (e == hipSuccess && R->has_big && !R->env_first.empty()) {
     R->env_first.push_back(0);  // the right-hand side's tile row is dense
     e = hipMemcpyAsync(R->big.first, R->env_first.data(), sizeof(int) * R->env_first.size(), hipMemcpyHostToDevice, s);
   }
-  if (e == hipSuccess) e = hipStreamSynchronize(s);  // staging is reused by the next call
+  // The staging buffer is reused by the next call: a resident upload waits for the copy here; a one-shot solve goes
+  // straight on to queue its kernels behind it and waits once, at its end (hipba_solve_batched, also when it fails).
+  if (e == hipSuccess && !use_handle_arena) e = hipStreamSynchronize(s);
   if (e != hipSuccess) return fail(HIPBA_ERR_HIP, "upload failed: %s", hipGetErrorString(e));
   *out = owner.release();
   return HIPBA_OK;
@@ -1534,6 +1538,7 @@ int hipba_solve_batched(hipba_handle h, int32_t n_windows, hipba_problem* proble
     hipba_device_problem_s* R = raw;
     const double t1 = now_s();
     rc = run_lm(h, R, o, nullptr, summaries, true);
+    if (rc) (void)hipStreamSynchronize(h->stream);  // nothing queued may outlive the buffers of this call
     if (!rc) rc = download_all(h, R, problems, summaries);
     const long long upload_bytes = R->upload_bytes, d2h_bytes = R->d2h_bytes + 4ll * (n_windows > 0 ? summaries[0].num_linear_solves : 0);
     owner.reset();
