@@ -407,8 +407,9 @@ constexpr int kYW = 19;
 
 // Pair products of one block: a lane group takes whole runs (same destination), sums each in registers
 // and adds it to the reduced matrix once.  WIDE: twelve lanes per product, three outputs each, the three
-// atomics of a group covering 96 contiguous bytes of the destination block (for S in HBM).  Otherwise two
-// lanes per product, lane h owning columns 3h..3h+2 (for S in LDS: half the LDS bytes read per multiply-add).
+// atomics of a group covering 96 contiguous bytes of the destination block (for S in HBM).  Otherwise one
+// lane per run (for S in LDS, where the phase is bound by its LDS reads: 36 reads per 108 multiply-adds instead of the
+// 27 per 54 of two lanes sharing a product).
 template <bool WIDE>
 __device__ __forceinline__ void pair_products(const unsigned short* pairs, const RunDesc* runs, int n_runs,
                                               const double* sYW, double* Sbase, int t) {
@@ -442,39 +443,35 @@ __device__ __forceinline__ void pair_products(const unsigned short* pairs, const
       for (int m = 0; m < 3; ++m) atomic_add_f64(dst + 6 * (a0 + 2 * m), -acc[m]);
     }
   } else {
-    const int grp = t >> 1, h = t & 1;
-    for (int r = grp; r < n_runs; r += kBlock / 2) {
+    for (int r = t; r < n_runs; r += kBlock) {
       const RunDesc rd = runs[r];
       const int off = rd.first_count >> 8, cnt = rd.first_count & 0xff;
       unsigned short pr[kRunMax];
 #pragma unroll
       for (int q = 0; q < kRunMax; ++q) pr[q] = pairs[off + q];
-      double acc[18];
+      double acc[36];
 #pragma unroll
-      for (int i = 0; i < 18; ++i) acc[i] = 0.0;
+      for (int i = 0; i < 36; ++i) acc[i] = 0.0;
 #pragma unroll
       for (int q = 0; q < kRunMax; ++q) {
         if (q < cnt) {
           const int i = pr[q] & 0xff, j = pr[q] >> 8;
           const double* Yi = sYW + kYW * i;
-          const double* Wj = sYW + kYW * j + 9 * h;
-          double wj[9];
+          const double* Wj = sYW + kYW * j;
+          double wj[18];
 #pragma unroll
-          for (int ii = 0; ii < 9; ++ii) wj[ii] = Wj[ii];
+          for (int ii = 0; ii < 18; ++ii) wj[ii] = Wj[ii];
 #pragma unroll
           for (int a = 0; a < 6; ++a) {
             const double y0 = Yi[3 * a], y1 = Yi[3 * a + 1], y2 = Yi[3 * a + 2];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) acc[3 * a + c] += y0 * wj[3 * c] + y1 * wj[3 * c + 1] + y2 * wj[3 * c + 2];
+            for (int c = 0; c < 6; ++c) acc[6 * a + c] += y0 * wj[3 * c] + y1 * wj[3 * c + 1] + y2 * wj[3 * c + 2];
           }
         }
       }
-      double* dst = Sbase + 36ll * rd.dest + 3 * h;
+      double* dst = Sbase + 36ll * rd.dest;
 #pragma unroll
-      for (int a = 0; a < 6; ++a) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) atomic_add_f64(dst + 6 * a + c, -acc[3 * a + c]);
-      }
+      for (int a = 0; a < 36; ++a) atomic_add_f64(dst + a, -acc[a]);
     }
   }
 }
@@ -485,8 +482,8 @@ __device__ __forceinline__ void pair_products(const unsigned short* pairs, const
 //   recomputing each from the record and the two poses (no atomics on S, fixed order).
 // MODE 1 / 3 (windows of at most kSmallMaxN/6 poses): `parts` workgroups per window, each walking every
 //   parts-th block of the window; b is accumulated in LDS and flushed once per workgroup, and so is the
-//   whole packed S when it fits (MODE 1; MODE 3 sends S to HBM with atomics).  A product is shared by two
-//   lanes (6x3 outputs each) instead of twelve, which halves the LDS bytes read per multiply-add.
+//   whole packed S when it fits (MODE 1; MODE 3 sends S to HBM with atomics).  With S in LDS a lane forms whole
+//   products (one run each) instead of sharing one with eleven others: a third of the LDS bytes read per multiply-add.
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_point_schur(DevP P, LmParams lm, int parts) {
   constexpr bool SMALL = MODE == 1 || MODE == 3;
