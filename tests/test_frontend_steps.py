@@ -34,6 +34,22 @@ def test_oracle_triangulation_reprojects_and_lifts_to_the_world(oracle):
     assert np.abs(world - want).max() <= 1e-12 * (1.0 + np.abs(want).max())
 
 
+def test_oracle_triangulation_matches_lapack_svd(oracle):
+    """An independent implementation of the same published method: numpy's (LAPACK) SVD of the 4x4 system, last row
+    of V^T, rounded to float and divided by w in float -- with matching noise in both images, so that the system has
+    no exact null vector and the answer is the least-squares one."""
+    left, right, _, _ = scenes.stereo_matches(3, 4000, pixel_sigma=0.5)
+    got = oracle.triangulate_stereo(scenes.P_LEFT, scenes.P_RIGHT, left, right)
+    l, r = left.astype(np.float64), right.astype(np.float64)
+    A = np.stack([l[:, 0:1] * scenes.P_LEFT[2] - scenes.P_LEFT[0], l[:, 1:2] * scenes.P_LEFT[2] - scenes.P_LEFT[1],
+                  r[:, 0:1] * scenes.P_RIGHT[2] - scenes.P_RIGHT[0], r[:, 1:2] * scenes.P_RIGHT[2] - scenes.P_RIGHT[1]], axis=1)
+    h = np.linalg.svd(A)[2][:, 3, :].astype(np.float32)
+    want = (h[:, :3] * (np.float32(1.0) / h[:, 3:4])).astype(np.float64)
+    # a rounding to float that falls the other way is 6e-8 of a component, twice
+    assert np.abs(got - want).max(axis=1).max() <= 3e-7 * np.abs(want).max()
+    assert (np.abs(got - want).max(axis=1) <= 3e-7 * np.linalg.norm(want, axis=1)).all()
+
+
 def test_oracle_triangulation_keeps_points_at_infinity_and_behind(oracle):
     # zero disparity: w = 0 after rounding to float, the point stays undivided (convertPointsFromHomogeneous);
     # negative disparity: a point behind the cameras comes out as it is (triangulator.cpp:48-59 filters nothing)
