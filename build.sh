@@ -28,3 +28,5 @@ g++ -O2 -std=c++17 -Wall -Iinclude -I$SRC/host -o $OUT/kitti_info $SRC/host/kitt
 echo "built $OUT/kitti_info"
 g++ -O2 -std=c++17 -Wall -pthread -Iinclude -I$SRC/host -o $OUT/ba_sequences $SRC/host/ba_sequences_cli.cpp -L$OUT -lhipba -Wl,-rpath,'$ORIGIN'
 echo "built $OUT/ba_sequences"
+g++ -O2 -std=c++17 -Wall -pthread -Iinclude -I$SRC/host -o $OUT/host_selftest $SRC/host/host_selftest.cpp -L$OUT -lhipba -Wl,-rpath,'$ORIGIN'
+echo "built $OUT/host_selftest"

@@ -150,3 +150,16 @@ def test_pose_order_is_a_permutation_and_keeps_a_keyframe_sequence_in_order():
     spread_natural = (cam.max(axis=1) - cam.min(axis=1)).max()
     spread_ordered = (pos[cam].max(axis=1) - pos[cam].min(axis=1)).max()
     assert spread_ordered < 0.75 * spread_natural
+
+
+def test_cpp_host_headers_selftest(tmp_path):
+    """The C++ host side checked in C++ (no GPU): map window and landmark clean-up (map.cpp:8-50), flattening of a map
+    into the C ABI's arrays and back (optimizer.cpp:19-52), the stage around the optimizer with bundle adjustment off
+    (frontend.cpp:65-84), window files, the KITTI text readers (parse_KITTI.cpp:14-113)."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "stereo_visual_odometry_amd", "lib",
+                       "host_selftest")
+    assert os.path.exists(exe), "run ./build.sh"
+    out = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert " 0 failed" in out.stdout
