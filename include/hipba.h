@@ -322,6 +322,22 @@ int hipba_refine_pose(hipba_handle h, double fx, double fy, double cx, double cy
                       const double* points, const double* uv, const uint8_t* use, double pose[7],
                       const hipba_options* options, hipba_summary* summary);
 
+/*
+ * The whole of cv::solvePnPRansac(points_3d, points_2d, K, coeffs, rvec, tvec, false, iterations, reprojection_error,
+ * confidence, inliers) as the reference calls it (src/solve/estimator.cpp:28-29: 1000 iterations, 3.0 px, 0.99), with
+ * two differences that the GPU makes natural.  Minimal samples (four matches) are solved by Gauss-Newton from a prior
+ * instead of in closed form, so the call takes one: pose, in = a pose near the answer (frame_prev_->pose_: the frames
+ * of a sequence are a fraction of a metre apart), out = the result, camera-to-world as estimator.cpp:58-59 has it.
+ * And every one of the `iterations` hypotheses is evaluated, all at once, instead of stopping by a confidence bound.
+ * The hypothesis with the most matches inside reprojection_error wins (the lowest number among equals), `inliers`
+ * ([n] bytes, may be NULL) marks them, *n_inliers counts them; with refine != 0 the pose is then refined on them
+ * (hipba_refine_pose).  The sampling is a counter-based generator: the same seed gives the same hypotheses on any
+ * machine.  HIPBA_ERR_INVALID_ARGUMENT with fewer than 4 matches.
+ */
+int hipba_pnp_ransac(hipba_handle h, double fx, double fy, double cx, double cy, int32_t camera_model, int64_t n,
+                     const double* points, const double* uv, double pose[7], int32_t iterations,
+                     double reprojection_error, uint64_t seed, int32_t refine, uint8_t* inliers, int64_t* n_inliers);
+
 /* ---- native RCCL communicator for sharded solves ------------------------------------------ */
 /*
  * A hipba_comm whose all-reduce is ncclAllReduce (RCCL over xGMI) queued on the engine's stream: for C / C++

@@ -248,3 +248,66 @@ def triangulate_stereo(P_left, P_right, left_uv, right_uv, pose=None):
     lib().oracle_triangulate_stereo(_d(pl), _d(pr), l.shape[0], l.ctypes.data_as(fp), r.ctypes.data_as(fp),
                                   None if ps is None else _d(ps), _d(out))
     return out
+
+
+def _splitmix64(state):
+    state = (state + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    z = state
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return state, z ^ (z >> 31)
+
+
+def pnp_ransac(K, points, uv, prior, iterations=1000, reprojection_error=3.0, seed=0, camera_model=Z_FORWARD):
+    """PnP by random sample consensus the way the engine's hipba_pnp_ransac states it (estimator.cpp:28-29 calls
+    cv::solvePnPRansac; OpenCV is absent, PARITY UNPINNED): per hypothesis four matches from a splitmix64 stream seeded
+    by (seed, hypothesis number), at most ten Gauss-Newton steps on their reprojection error from `prior` (normal
+    equations with a 1e-9 relative damping, solved exactly), then the count of matches within the threshold; the
+    hypothesis with the most wins, the lowest number among equals.  Returns (pose before any refinement, mask, counts).
+    Python loops over the hypotheses: for the small cases of tests."""
+    pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+    px = np.ascontiguousarray(uv, dtype=np.float64).reshape(-1, 2)
+    n = pts.shape[0]
+    thr2 = reprojection_error * reprojection_error
+    everything = Problem(np.asarray(prior, dtype=np.float64).reshape(1, 7), pts, np.zeros(n, dtype=np.int32),
+                         np.arange(n, dtype=np.int32), px, K, camera_model, None, np.ones(n, dtype=np.uint8))
+    counts = np.zeros(iterations, dtype=np.int64)
+    poses = np.zeros((iterations, 7))
+    for h in range(iterations):
+        state = (seed + 0xD1B54A32D192ED03 * (h + 1)) & 0xFFFFFFFFFFFFFFFF
+        idx = []
+        for k in range(4):
+            for _ in range(16):
+                state, z = _splitmix64(state)
+                cand = z % n
+                if cand not in idx:
+                    break
+            idx.append(cand)
+        ii = np.array(idx)
+        pose = np.asarray(prior, dtype=np.float64).reshape(7).copy()
+        for _ in range(10):
+            mini = Problem(pose.reshape(1, 7), pts[ii], np.zeros(4, dtype=np.int32), np.arange(4, dtype=np.int32), px[ii], K,
+                           camera_model, None, np.ones(4, dtype=np.uint8))
+            e = evaluate(mini, JAC_ANALYTIC, apply_loss=False)
+            J = e["jac_pose"].reshape(8, 6)
+            r = e["residuals"].reshape(8)
+            H = J.T @ J
+            H[np.diag_indices(6)] += 1e-9 * (1.0 + np.diag(H))
+            try:
+                L = np.linalg.cholesky(H)
+            except np.linalg.LinAlgError:
+                break
+            d = -np.linalg.solve(L.T, np.linalg.solve(L, J.T @ r))
+            if not np.isfinite(d).all():
+                break
+            pose = se3_plus(pose, d)
+            if not (d @ d > 1e-24):
+                break
+        everything.poses[0] = pose
+        res = evaluate(everything, JAC_ANALYTIC, apply_loss=False)["residuals"]
+        counts[h] = int(((res * res).sum(axis=1) < thr2).sum())
+        poses[h] = pose
+    best = int(np.argmax(counts))  # the first of equals
+    everything.poses[0] = poses[best]
+    res = evaluate(everything, JAC_ANALYTIC, apply_loss=False)["residuals"]
+    return poses[best].copy(), ((res * res).sum(axis=1) < thr2).astype(np.uint8), counts

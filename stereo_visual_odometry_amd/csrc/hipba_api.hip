@@ -1878,8 +1878,61 @@ int hipba_refine_pose(hipba_handle h, double fx, double fy, double cx, double cy
     p.n_points = (int32_t)m; p.points = pts.data(); p.point_const = point_const.data();
     p.n_obs = (int64_t)m; p.obs_pose = obs_pose.data(); p.obs_point = obs_point.data(); p.obs_uv = px.data();
     p.fx = fx; p.fy = fy; p.cx = cx; p.cy = cy; p.camera_model = camera_model;
-    hipba_summary local;
+    hipba_summary local{};  // (iteration_log = null: the solve writes no log)
     return hipba_solve(h, &p, options, summary ? summary : &local);
+  });
+}
+
+int hipba_pnp_ransac(hipba_handle h, double fx, double fy, double cx, double cy, int32_t camera_model, int64_t n,
+                     const double* points, const double* uv, double pose[7], int32_t iterations,
+                     double reprojection_error, uint64_t seed, int32_t refine, uint8_t* inliers, int64_t* n_inliers) {
+  return guarded([&]() -> int {
+    if (!h || !pose || !points || !uv) return fail(HIPBA_ERR_INVALID_ARGUMENT, "null argument");
+    if (n < 4) return fail(HIPBA_ERR_INVALID_ARGUMENT, "PnP by sample consensus needs at least 4 matches (got %lld)", (long long)n);
+    if (iterations <= 0 || iterations > (1 << 20)) return fail(HIPBA_ERR_INVALID_ARGUMENT, "iterations out of range (%d)", iterations);
+    if (!(reprojection_error > 0.0)) return fail(HIPBA_ERR_INVALID_ARGUMENT, "reprojection_error must be positive");
+    if (camera_model != HIPBA_CAMERA_Z_FORWARD && camera_model != HIPBA_CAMERA_X_FORWARD)
+      return fail(HIPBA_ERR_INVALID_ARGUMENT, "unknown camera model %d", camera_model);
+    HIPBA_HIP(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    // one staging block up: [prior 8][points 3n][uv 2n]; device work area behind it: counts, poses, result, mask
+    const size_t up_bytes = sizeof(double) * (8 + 5 * (size_t)n);
+    const size_t count_bytes = align_up(sizeof(int) * (size_t)iterations, 256);
+    const size_t poses_bytes = align_up(sizeof(double) * 7 * (size_t)iterations, 256);
+    const size_t mask_bytes = align_up((size_t)n, 256);
+    const size_t up_al = align_up(up_bytes, 256);
+    int rc = ensure_staging(h, std::max(up_bytes, 256 + mask_bytes));
+    if (rc) return rc;
+    rc = ensure_arena(h, up_al + count_bytes + poses_bytes + 256 + mask_bytes);
+    if (rc) return rc;
+    double* st = static_cast<double*>(h->staging);
+    for (int i = 0; i < 7; ++i) st[i] = pose[i];
+    st[7] = 0.0;
+    memcpy(st + 8, points, sizeof(double) * 3 * (size_t)n);
+    memcpy(st + 8 + 3 * (size_t)n, uv, sizeof(double) * 2 * (size_t)n);
+    char* dv = static_cast<char*>(h->arena);
+    HIPBA_HIP(hipMemcpyAsync(dv, st, up_bytes, hipMemcpyHostToDevice, s));
+    const double* d_prior = reinterpret_cast<const double*>(dv);
+    const double* d_pts = d_prior + 8;
+    const double* d_uv = d_pts + 3 * (size_t)n;
+    int* d_count = reinterpret_cast<int*>(dv + up_al);
+    double* d_poses = reinterpret_cast<double*>(dv + up_al + count_bytes);
+    double* d_out = reinterpret_cast<double*>(dv + up_al + count_bytes + poses_bytes);
+    unsigned char* d_mask = reinterpret_cast<unsigned char*>(dv + up_al + count_bytes + poses_bytes + 256);
+    const CameraK K{fx, fy, cx, cy, camera_model};
+    HIPBA_HIP(launch_pnp_ransac(K, n, d_pts, d_uv, d_prior, iterations, seed, reprojection_error, d_count, d_poses, d_out,
+                                d_mask, s));
+    // result and mask come back in one copy (they are adjacent in the work area)
+    HIPBA_HIP(hipMemcpyAsync(st, d_out, 256 + (size_t)n, hipMemcpyDeviceToHost, s));
+    HIPBA_HIP(hipStreamSynchronize(s));
+    const long long best = (long long)st[7];
+    for (int i = 0; i < 7; ++i) pose[i] = st[i];
+    const unsigned char* mask = reinterpret_cast<const unsigned char*>(st) + 256;
+    std::vector<uint8_t> keep(mask, mask + n);  // (the refinement below reuses the staging buffer)
+    if (inliers) memcpy(inliers, keep.data(), (size_t)n);
+    if (n_inliers) *n_inliers = best;
+    if (refine && best >= 3) return hipba_refine_pose(h, fx, fy, cx, cy, camera_model, n, points, uv, keep.data(), pose, nullptr, nullptr);
+    return HIPBA_OK;
   });
 }
 

@@ -7,6 +7,7 @@
 // One lane per match here; the three steps never leave registers.
 #include <hip/hip_runtime.h>
 
+#include "ba_math.hpp"
 #include "hipba_internal.hpp"
 
 namespace hipba {
@@ -120,6 +121,156 @@ hipError_t launch_triangulate_stereo(const double* d_pl, const double* d_pr, lon
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_triangulate_stereo, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_pl, d_pr, n,
                      reinterpret_cast<const float2*>(d_left), reinterpret_cast<const float2*>(d_right), d_pose, d_out);
+  return hipGetLastError();
+}
+
+// ---- PnP by random sample consensus (src/solve/estimator.cpp:28-29: cv::solvePnPRansac) -----------------------------
+// One lane per hypothesis: four matches drawn with a counter-based generator (the same draw for the same seed and
+// hypothesis number wherever it runs), the pose that fits them by Gauss-Newton on the reprojection error from the
+// caller's prior (consecutive frames of a sequence: the prior is the previous frame's pose), then the number of matches
+// the pose reprojects within the threshold.  A second launch picks the hypothesis with the most (the lowest number
+// among equals) and marks its inliers.  OpenCV solves its minimal samples in closed form and stops early by a
+// confidence bound; here every hypothesis is evaluated, all at once.
+__host__ __device__ __forceinline__ unsigned long long splitmix64(unsigned long long& state) {
+  unsigned long long z = (state += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+constexpr int kPnpSample = 4;
+constexpr int kPnpGaussNewton = 10;
+
+__global__ __launch_bounds__(64) void k_pnp_hypotheses(CameraK K, long long n, const double* __restrict__ pts,
+                                                       const double* __restrict__ uv, const double* __restrict__ prior,
+                                                       int n_hyp, unsigned long long seed, double thr2, int* __restrict__ count,
+                                                       double* __restrict__ poses) {
+  const int h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= n_hyp) return;
+  unsigned long long state = seed + 0xD1B54A32D192ED03ull * (unsigned long long)(h + 1);
+  long long idx[kPnpSample];
+  for (int k = 0; k < kPnpSample; ++k) {
+    for (int attempt = 0; attempt < 16; ++attempt) {
+      idx[k] = (long long)(splitmix64(state) % (unsigned long long)n);
+      bool fresh = true;
+      for (int j = 0; j < k; ++j) fresh = fresh && idx[j] != idx[k];
+      if (fresh) break;
+    }
+  }
+  double pose[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) pose[i] = prior[i];
+  for (int it = 0; it < kPnpGaussNewton; ++it) {
+    double H[21], g[6];
+#pragma unroll
+    for (int i = 0; i < 21; ++i) H[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) g[i] = 0.0;
+    for (int k = 0; k < kPnpSample; ++k) {
+      double r[2], Jc[12], Jp[6];
+      residual_jacobian(K, pose, pts + 3 * idx[k], uv[2 * idx[k]], uv[2 * idx[k] + 1], r, Jc, Jp);
+      int q = 0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+#pragma unroll
+        for (int j = i; j < 6; ++j) { H[q] += Jc[i] * Jc[j] + Jc[6 + i] * Jc[6 + j]; ++q; }
+        g[i] += Jc[i] * r[0] + Jc[6 + i] * r[1];
+      }
+    }
+    // Cholesky of the 6x6 normal matrix (upper triangle packed row by row), a whisker of damping against a
+    // degenerate sample; a sample it cannot factor keeps the pose it has
+    double L[6][6];
+    bool ok = true;
+    {
+      int q = 0;
+      for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 6; ++j) { L[j][i] = H[q] + (i == j ? 1e-9 * (1.0 + H[q]) : 0.0); ++q; }
+    }
+    for (int j = 0; j < 6 && ok; ++j) {
+      double d = L[j][j];
+      for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
+      if (!(d > 0.0) || !isfinite(d)) { ok = false; break; }
+      d = sqrt(d);
+      L[j][j] = d;
+      for (int i = j + 1; i < 6; ++i) {
+        double v = L[i][j];
+        for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k];
+        L[i][j] = v / d;
+      }
+    }
+    if (!ok) break;
+    double y[6], dlt[6];
+    for (int i = 0; i < 6; ++i) {
+      double v = -g[i];
+      for (int k = 0; k < i; ++k) v -= L[i][k] * y[k];
+      y[i] = v / L[i][i];
+    }
+    for (int i = 5; i >= 0; --i) {
+      double v = y[i];
+      for (int k = i + 1; k < 6; ++k) v -= L[k][i] * dlt[k];
+      dlt[i] = v / L[i][i];
+    }
+    double next[7], step2 = 0.0;
+    se3_plus(pose, dlt, next);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) pose[i] = next[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) step2 += dlt[i] * dlt[i];
+    if (!(step2 > 1e-24)) break;  // converged (or not a number: the count below is zero then)
+  }
+  int c = 0;
+  for (long long j = 0; j < n; ++j) {
+    double r[2];
+    residual_only(K, pose, pts + 3 * j, uv[2 * j], uv[2 * j + 1], r);
+    c += (r[0] * r[0] + r[1] * r[1] < thr2) ? 1 : 0;
+  }
+  count[h] = c;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) poses[7ll * h + i] = pose[i];
+}
+
+// out: [0..6] the best hypothesis' pose, [7] its inlier count (as a double); mask: one byte per match
+__global__ __launch_bounds__(256) void k_pnp_select(CameraK K, long long n, const double* __restrict__ pts,
+                                                    const double* __restrict__ uv, int n_hyp, const int* __restrict__ count,
+                                                    const double* __restrict__ poses, double thr2, double* __restrict__ out,
+                                                    unsigned char* __restrict__ mask) {
+  __shared__ int best_count[256], best_index[256];
+  const int t = threadIdx.x;
+  int bc = -1, bi = 0x7fffffff;
+  for (int h = t; h < n_hyp; h += 256) {
+    const int c = count[h];
+    if (c > bc) { bc = c; bi = h; }  // (ascending h: the first of equals stays)
+  }
+  best_count[t] = bc; best_index[t] = bi;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (t < s) {
+      const int oc = best_count[t + s], oi = best_index[t + s];
+      if (oc > best_count[t] || (oc == best_count[t] && oi < best_index[t])) { best_count[t] = oc; best_index[t] = oi; }
+    }
+    __syncthreads();
+  }
+  const int best = best_index[0];
+  double pose[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) pose[i] = poses[7ll * best + i];
+  if (t < 7) out[t] = pose[t];
+  if (t == 7) out[7] = (double)best_count[0];
+  for (long long j = t; j < n; j += 256) {
+    double r[2];
+    residual_only(K, pose, pts + 3 * j, uv[2 * j], uv[2 * j + 1], r);
+    mask[j] = (r[0] * r[0] + r[1] * r[1] < thr2) ? 1 : 0;
+  }
+}
+
+hipError_t launch_pnp_ransac(const CameraK& K, long long n, const double* d_pts, const double* d_uv, const double* d_prior,
+                             int n_hyp, unsigned long long seed, double reprojection_error, int* d_count, double* d_poses,
+                             double* d_out, unsigned char* d_mask, hipStream_t s) {
+  const double thr2 = reprojection_error * reprojection_error;
+  hipLaunchKernelGGL(k_pnp_hypotheses, dim3((unsigned)((n_hyp + 63) / 64)), dim3(64), 0, s, K, n, d_pts, d_uv, d_prior, n_hyp,
+                     seed, thr2, d_count, d_poses);
+  hipLaunchKernelGGL(k_pnp_select, dim3(1), dim3(256), 0, s, K, n, d_pts, d_uv, n_hyp, (const int*)d_count,
+                     (const double*)d_poses, thr2, d_out, d_mask);
   return hipGetLastError();
 }
 

@@ -97,7 +97,7 @@ EXPORTED_SYMBOLS = [
     "hipba_solve", "hipba_solve_batched", "hipba_evaluate", "hipba_evaluate_device", "hipba_upload", "hipba_upload_shard", "hipba_pose_order", "hipba_reset", "hipba_solve_device",
     "hipba_solve_device_sharded", "hipba_download", "hipba_free_problem", "hipba_time_kernel", "hipba_reduced_solve_flops",
     "hipba_rccl_get_unique_id", "hipba_rccl_comm_create", "hipba_rccl_comm_stats", "hipba_rccl_comm_destroy",
-    "hipba_triangulate_stereo", "hipba_triangulate_stereo_device", "hipba_refine_pose",
+    "hipba_triangulate_stereo", "hipba_triangulate_stereo_device", "hipba_refine_pose", "hipba_pnp_ransac",
 ]
 
 
@@ -180,6 +180,8 @@ def load_library(path=None):
                                                     C.c_void_p, C.c_void_p]
     lib.hipba_refine_pose.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int64,
                                       _dp, _dp, _bp, _dp, C.POINTER(COptions), C.POINTER(CSummary)]
+    lib.hipba_pnp_ransac.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int64, _dp, _dp,
+                                     _dp, C.c_int32, C.c_double, C.c_uint64, C.c_int32, _bp, C.POINTER(C.c_int64)]
     lib.hipba_evaluate_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double,
                                           C.c_double, C.c_int32, C.POINTER(COptions), C.c_int, C.c_void_p, C.c_void_p,
@@ -457,6 +459,23 @@ class Solver:
                                            None if mask is None else mask.ctypes.data_as(_bp), ps.ctypes.data_as(_dp),
                                            C.byref(o), C.byref(summ)))
         return ps, _summary_dict(summ)
+
+    def pnp_ransac(self, K, points, uv, pose, iterations=1000, reprojection_error=3.0, seed=0, refine=True,
+                   camera_model=CAMERA_Z_FORWARD):
+        """hipba_pnp_ransac (cv::solvePnPRansac as estimator.cpp:28-29 calls it, from a prior pose): (pose, inlier mask)."""
+        pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+        px = np.ascontiguousarray(uv, dtype=np.float64).reshape(-1, 2)
+        if pts.shape[0] != px.shape[0]:
+            raise ValueError("points and uv differ in length")
+        ps = np.ascontiguousarray(pose, dtype=np.float64).reshape(7).copy()
+        mask = np.zeros(pts.shape[0], dtype=np.uint8)
+        cnt = C.c_int64(0)
+        _check(self._lib.hipba_pnp_ransac(self._h, K[0], K[1], K[2], K[3], camera_model, pts.shape[0],
+                                          pts.ctypes.data_as(_dp), px.ctypes.data_as(_dp), ps.ctypes.data_as(_dp),
+                                          int(iterations), float(reprojection_error), int(seed), int(bool(refine)),
+                                          mask.ctypes.data_as(_bp), C.byref(cnt)))
+        assert cnt.value == int(mask.sum())
+        return ps, mask
 
     def upload(self, problems):
         if isinstance(problems, Problem):

@@ -151,3 +151,35 @@ def test_pose_refinement_rejects_too_few_matches(solver):
     mask[:2] = 1
     with pytest.raises(hipba.HipbaError):
         solver.refine_pose(scenes.KITTI_K, pts, uv, start, use=mask)
+
+
+@pytest.mark.gpu
+def test_pnp_ransac_matches_oracle_and_finds_the_inliers(solver, oracle):
+    # 30 % gross outliers; the prior is half a metre and two degrees off, as the previous frame's pose would be
+    pts, uv, start, true, truth_mask = scenes.pnp_case(21, n=300, outlier_fraction=0.3, sigma_t=0.3, sigma_w=0.02)
+    pose, mask = solver.pnp_ransac(scenes.KITTI_K, pts, uv, start, iterations=200, reprojection_error=3.0, seed=7, refine=False)
+    o_pose, o_mask, o_counts = oracle.pnp_ransac(scenes.KITTI_K, pts, uv, start, iterations=200, reprojection_error=3.0, seed=7)
+    # the same samples, the same Gauss-Newton: the same winner, pose to rounding, the same inliers
+    assert np.abs(pose - o_pose).max() <= 1e-8
+    assert (mask != o_mask).sum() <= 1 and int(mask.sum()) >= int(o_counts.max()) - 1
+    # the consensus set is the true inlier set (0.3 px noise against a 3 px threshold; outliers are uniform in the image)
+    assert (mask[truth_mask == 1] == 1).mean() > 0.99 and (mask[truth_mask == 0] == 1).mean() < 0.02
+    # refined on the consensus set the pose is the one the true inliers give
+    refined, mask2 = solver.pnp_ransac(scenes.KITTI_K, pts, uv, start, iterations=200, reprojection_error=3.0, seed=7)
+    want, _ = solver.refine_pose(scenes.KITTI_K, pts, uv, pose, use=mask)
+    assert np.array_equal(mask, mask2) and np.abs(refined - want).max() <= 1e-9
+    assert np.abs(refined[4:] - true[4:]).max() < 0.03 and np.abs(refined[:4] - true[:4]).max() < 2e-3
+    # another seed draws other samples and lands on the same consensus set
+    _, mask3 = solver.pnp_ransac(scenes.KITTI_K, pts, uv, start, iterations=200, seed=8)
+    assert (mask3 != mask).sum() <= 3
+
+
+@pytest.mark.gpu
+def test_pnp_ransac_rejects_bad_arguments(solver):
+    pts, uv, start, _, _ = scenes.pnp_case(22, n=10)
+    with pytest.raises(hipba.HipbaError):
+        solver.pnp_ransac(scenes.KITTI_K, pts[:3], uv[:3], start)
+    with pytest.raises(hipba.HipbaError):
+        solver.pnp_ransac(scenes.KITTI_K, pts, uv, start, iterations=0)
+    with pytest.raises(hipba.HipbaError):
+        solver.pnp_ransac(scenes.KITTI_K, pts, uv, start, reprojection_error=-1.0)
