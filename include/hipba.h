@@ -150,7 +150,8 @@ typedef struct hipba_summary {
   int32_t num_linear_solves;       /* trust-region steps computed; Ceres does not log the step on which a
                                       parameter/function-tolerance test ends the solve, so this can be
                                       num_iterations (= log entries) rather than num_iterations - 1 */
-  /* optional per-iteration log: caller-provided storage for iteration_log_capacity entries */
+  /* optional per-iteration log: caller-provided storage for iteration_log_capacity entries.  These two are INPUTS:
+     zero the struct (hipba_summary s = {0};) before a call that wants no log */
   hipba_iteration* iteration_log;
   int32_t iteration_log_capacity;
   int32_t reserved2;
