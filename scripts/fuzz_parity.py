@@ -12,7 +12,7 @@ from stereo_visual_odometry_amd import hipba, scenes
 
 def random_case(seed):
     rng = np.random.default_rng(seed)
-    n_frames = int(rng.choice([2, 3, 5, 8, 10, 13, 21, 22, 30, 33, 40]))
+    n_frames = int(rng.choice([2, 3, 5, 8, 10, 13, 21, 22, 30, 33, 40, 48, 64]))
     n_tracks = int(rng.choice([6, 40, 300, 300, 1500, 1500]))
     lo = int(rng.choice([1, 2, 3, 4], p=[0.1, 0.1, 0.4, 0.4]))
     lo = min(lo, n_frames)
@@ -49,9 +49,15 @@ def random_case(seed):
         k = rng.choice(uv.shape[0], 3, replace=False)
         op = np.concatenate([op, op[k]]); oq = np.concatenate([oq, oq[k]])
         uv = np.concatenate([uv, uv[k] + rng.normal(0.0, 0.3, (3, 2))])
+    if rng.uniform() < 0.3:
+        # the harness's camera (x forward, y left, z up: test/ba_test.h:179-211): the same scene with every camera frame
+        # turned by the fixed rotation that maps (x, y, z) to (z, -x, -y)
+        model = hipba.CAMERA_X_FORWARD
+        poses = poses.copy()
+        poses[:, :4] = scenes._quat_mul(poses[:, :4], np.array([0.5, -0.5, 0.5, 0.5]))
     prob = hipba.Problem(poses, points, op, oq, uv, scenes.KITTI_K, model, pose_const, point_const)
     opts = dict(max_num_iterations=int(rng.choice([5, 25, 60])), loss=loss, loss_scale=float(rng.choice([1.0, 2.5])))
-    return prob, opts, "frames %d tracks %d len %d-%d kind %d loss %d" % (n_frames, n_tracks, lo, hi, kind, loss)
+    return prob, opts, "frames %d tracks %d len %d-%d kind %d loss %d model %d" % (n_frames, n_tracks, lo, hi, kind, loss, model)
 
 
 def well_posed(prob):
