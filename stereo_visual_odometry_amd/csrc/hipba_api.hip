@@ -1349,6 +1349,11 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
     if (st.active) term = HIPBA_NO_CONVERGENCE;  // loop ended on max_num_iterations on the host side
     sm.termination_type = term;
     sm.num_iterations = st.iteration + 1;
+    // Ceres logs no iteration at all when there is nothing to optimise (no non-constant block in any residual: it
+    // reports convergence at the fixed cost without running the minimizer) or when the very first evaluation fails
+    if (R->meta[w].n_act_poses + R->meta[w].n_act_points == 0 || R->meta[w].n_act_obs == 0 ||
+        (term == HIPBA_FAILURE && st.iteration == 0 && st.num_linear_solves == 0))
+      sm.num_iterations = 0;
     sm.num_successful_steps = st.num_successful;
     sm.num_unsuccessful_steps = st.num_unsuccessful;
     sm.num_linear_solves = st.num_linear_solves;
