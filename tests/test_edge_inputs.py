@@ -68,3 +68,26 @@ def test_edge_inputs_match_oracle(solver, oracle):
             # (a landmark on the wrong side of its camera is pushed around freely: compared through the cost only)
             if name != "a landmark behind its camera":
                 assert np.abs(g.points - o.points).max() <= 1e-6, (name, np.abs(g.points - o.points).max())
+
+
+@pytest.mark.gpu
+def test_edge_inputs_batched_equal_one_by_one(solver):
+    """The same windows, failures and trivial ones among them, in ONE batched solve: every window ends as it does alone."""
+    cases = [(name, prob) for name, prob, kw in _cases() if not kw]
+    opts = hipba.default_options(max_num_iterations=20)
+    alone = []
+    for name, prob in cases:
+        g = prob.copy()
+        alone.append((solver.solve(g, opts), g))
+    dp = solver.upload([prob.copy() for _, prob in cases])
+    together = dp.solve(opts)
+    for w, (name, prob) in enumerate(cases):
+        s1, g1 = alone[w]
+        s2 = together[w]
+        poses, points = dp.download(w)
+        assert s1["termination_type"] == s2["termination_type"] and s1["num_iterations"] == s2["num_iterations"], name
+        if np.isfinite(s1["final_cost"]):
+            assert abs(s1["final_cost"] - s2["final_cost"]) <= 1e-9 * max(1.0, abs(s1["final_cost"])), name
+        if s1["termination_type"] != hipba.FAILURE:
+            assert np.abs(poses - g1.poses).max(initial=0.0) <= 1e-8, name
+    dp.free()
