@@ -1351,7 +1351,8 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
     sm.num_iterations = st.iteration + 1;
     // Ceres logs no iteration at all when there is nothing to optimise (no non-constant block in any residual: it
     // reports convergence at the fixed cost without running the minimizer) or when the very first evaluation fails
-    if (R->meta[w].n_act_poses + R->meta[w].n_act_points == 0 || R->meta[w].n_act_obs == 0 ||
+    // (a rank of a sharded solve cannot tell the first case from its own shard: it reports what the job did)
+    if ((!sharded && (R->meta[w].n_act_poses + R->meta[w].n_act_points == 0 || R->meta[w].n_act_obs == 0)) ||
         (term == HIPBA_FAILURE && st.iteration == 0 && st.num_linear_solves == 0))
       sm.num_iterations = 0;
     sm.num_successful_steps = st.num_successful;

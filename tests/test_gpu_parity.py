@@ -477,6 +477,23 @@ def test_sharded_tile_exchange_in_one_piece_and_pipelined(monkeypatch):
     assert all(count < tile_words for count, _, on_engine in traces[None] if on_engine)
 
 
+def test_sharded_solve_with_an_empty_shard():
+    """A rank whose landmark block nobody observes goes through every collective of the job all the same and ends
+    with the job's result."""
+    prob, _, _ = scenes.bal_scale(seed=5, grid=(6, 7), n_points=3000, depth_lo=5.0, depth_hi=25.0)
+    full = hipba.Problem(prob.poses, np.concatenate([prob.points, prob.points + 1.0]), prob.obs_pose, prob.obs_point,
+                         prob.obs_uv, prob.K, prob.camera_model, prob.pose_const, None)
+    opts = lambda: hipba.default_options(max_num_iterations=6)
+    ref = full.copy()
+    sv = hipba.Solver(0)
+    s_ref = sv.solve(ref, opts())
+    sv.close()
+    for s, poses, pts, lo, hi in run_threaded_ranks(full, opts, timeout=120):
+        assert s["termination_type"] == s_ref["termination_type"] and s["num_iterations"] == s_ref["num_iterations"] > 1
+        assert abs(s["final_cost"] - s_ref["final_cost"]) <= 1e-9 * s_ref["final_cost"]
+        assert np.abs(poses - ref.poses).max() <= 1e-8 and np.abs(pts - ref.points[lo:hi]).max() <= 1e-7
+
+
 def test_sharded_tile_exchange_three_ranks():
     """Three ranks (an odd count: uneven landmark blocks, envelopes merged over more than two contributions)."""
     prob = scenes.bal_scale(seed=38, grid=(60, 4), n_points=180000, depth_lo=5.0, depth_hi=15.0)[0]
