@@ -91,3 +91,40 @@ def test_edge_inputs_batched_equal_one_by_one(solver):
         if s1["termination_type"] != hipba.FAILURE:
             assert np.abs(poses - g1.poses).max(initial=0.0) <= 1e-8, name
     dp.free()
+
+
+@pytest.mark.gpu
+def test_repeated_calls_hold_device_memory_steady(solver):
+    """A frontend calls the engine once per frame for hours (src/frontend.cpp:65-84): after one pass over every kind of
+    call has sized the handle's arena, further passes take no device memory (the same bytes are free before and after)."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+
+    def free_bytes():
+        f, t = C.c_size_t(0), C.c_size_t(0)
+        assert hip.hipMemGetInfo(C.byref(f), C.byref(t)) == 0
+        return f.value
+
+    rng = np.random.default_rng(3)
+    wins = [scenes.small_window(300 + i, n_frames=int(rng.integers(3, 12)), n_points=int(rng.integers(50, 1200)))[0]
+            for i in range(12)]
+    opts = hipba.reference_production_options()
+
+    def one_pass(rep):
+        for w in wins:
+            solver.solve(w.copy(), opts)
+        dp = solver.upload([w.copy() for w in wins[:6]])
+        dp.solve(opts)
+        dp.reset()
+        dp.solve(opts)
+        dp.free()
+        pts, uv, start, _, _ = scenes.pnp_case(rep, n=300, outlier_fraction=0.2)
+        solver.pnp_ransac(scenes.KITTI_K, pts, uv, start, iterations=200, seed=rep)
+        left, right, _, pose = scenes.stereo_matches(rep, 5000)
+        solver.triangulate_stereo(scenes.P_LEFT, scenes.P_RIGHT, left, right, pose)
+
+    one_pass(0)
+    before = free_bytes()
+    for rep in range(1, 6):
+        one_pass(rep)
+    assert free_bytes() == before
