@@ -323,12 +323,26 @@ int validate_problem(const hipba_problem& p, int w) {
   return HIPBA_OK;
 }
 
+// development aid (-DHIPBA_SETUP_TIMING): host time between the marks of build_resident, to stderr
+#ifdef HIPBA_SETUP_TIMING
+struct SetupClock {
+  double t = now_s();
+  void mark(const char* what) { const double n = now_s(); fprintf(stderr, "setup %-16s %7.1f us\n", what, 1e6 * (n - t)); t = now_s(); }
+};
+#define SETUP_CLOCK() SetupClock setup_clock
+#define SETUP_MARK(what) setup_clock.mark(what)
+#else
+#define SETUP_CLOCK() do {} while (0)
+#define SETUP_MARK(what) do {} while (0)
+#endif
+
 // ---- analysis + upload -------------------------------------------------------------------------
 // pose_order (one-window problems, optional): the poses of the window in the order their blocks should take in the
 // reduced camera system (a permutation of 0 .. n_poses - 1; constant and unobserved ones are skipped).  Null: chosen
 // here (see camera_order.hpp).  Shards of one problem must all be given the same order.
 int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool use_handle_arena, int log_cap,
                    bool all_poses_active, hipba_device_problem_s** out, const int32_t* pose_order = nullptr) {
+  SETUP_CLOCK();
   for (int w = 0; w < nw; ++w) {
     int rc = validate_problem(probs[w], w);
     if (rc) return rc;
@@ -418,6 +432,7 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
                 max_ncam);
   }
 
+  SETUP_MARK("counts");
   // ---- observations: PM | VC | CC --------------------------------------------------------------
   std::vector<long long> pp_start(n_pm_points + 1, 0);
   for (long long gp = 0; gp < NPT; ++gp)
@@ -459,6 +474,7 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
     }
   }
 
+  SETUP_MARK("observations");
   // ---- order of the poses in the reduced system (one large window: the dense factorisation's envelope) --------
   const bool dense_path = nw == 1 && 6 * max_ncam > kSmallMaxN;
   if (dense_path) {
@@ -525,6 +541,7 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
     }
   }
 
+  SETUP_MARK("pose order");
   // ---- blocks + pair lists -----------------------------------------------------------------------
   std::vector<BlockDesc> blocks;
   std::vector<unsigned short> pairs;
@@ -648,6 +665,7 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   const int n_blk_cc = (int)blocks.size() - n_blk_pm - n_blk_vc;
   const int n_blocks = (int)blocks.size();
 
+  SETUP_MARK("blocks+pairs");
   // ---- gathered accumulation (one large window): observation pairs listed per destination block ---------
   // fp64 atomics into S run at ~1 TB/s of added bytes; beyond a few million 6x6 products it is faster to let
   // every block of S sum its own products, each recomputed from the landmark's record and the two poses.
@@ -717,6 +735,7 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
     pairs.assign(8, kPairPad);  // the blocks themselves need no pair lists in this mode
   }
 
+  SETUP_MARK("gathered lists");
   // ---- atomic / LDS accumulation: each block's pair list grouped by destination block and cut into runs
   // of at most kRunMax pairs with one destination; a lane group sums a run in registers and adds it to
   // the reduced matrix once ------------------------------------------------------------------------
@@ -854,6 +873,7 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
     runs.push_back(RunDesc{0, 0});
   }
 
+  SETUP_MARK("runs");
   // ---- camera-major lists ------------------------------------------------------------------------
   std::vector<long long> cm_start(n_slots + 1, 0);
   for (long long o = 0; o < n_act_obs; ++o) {
@@ -882,6 +902,7 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
     R->meta[w].dp_of.assign(dp_of.begin() + pt_base[w], dp_of.begin() + pt_base[w + 1]);
   }
 
+  SETUP_MARK("camera-major");
   // ---- parameters in device order ----------------------------------------------------------------
   std::vector<double> poses(std::max<long long>(7 * NP, 7)), points(std::max<long long>(3 * NPT, 3));
   for (int w = 0; w < nw; ++w) {
@@ -893,6 +914,7 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
     }
   }
 
+  SETUP_MARK("parameters");
   // ---- plan the arena ----------------------------------------------------------------------------
   P.n_poses = (int)NP; P.n_points = (int)NPT; P.n_act_poses = n_slots; P.n_pm_points = n_pm_points;
   P.n_pm_obs = n_pm_obs; P.n_act_obs = n_act_obs; P.n_all_obs = n_all;
@@ -961,6 +983,7 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   }
   const size_t total = work.total;
 
+  SETUP_MARK("plan");
   // ---- allocate + upload -------------------------------------------------------------------------
   int rc = HIPBA_OK;
   if (use_handle_arena) {
@@ -1014,6 +1037,7 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
     stage(d_chunk_start, chunk_start.data(), chunk_start.size() * 8);
   }
   hipStream_t s = h->stream;
+  SETUP_MARK("fill staging");
   hipError_t e = hipMemcpyAsync(R->arena, h->staging, upload_bytes, hipMemcpyHostToDevice, s);
   if (e == hipSuccess) e = hipMemcpyAsync(P.poses[1], P.poses[0], poses.size() * 8, hipMemcpyDeviceToDevice, s);
   if (e == hipSuccess) e = hipMemcpyAsync(P.points[1], P.points[0], points.size() * 8, hipMemcpyDeviceToDevice, s);
@@ -1030,6 +1054,7 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   // straight on to queue its kernels behind it and waits once, at its end (hipba_solve_batched, also when it fails).
   if (e == hipSuccess && !use_handle_arena) e = hipStreamSynchronize(s);
   if (e != hipSuccess) return fail(HIPBA_ERR_HIP, "upload failed: %s", hipGetErrorString(e));
+  SETUP_MARK("queue copies");
   *out = owner.release();
   return HIPBA_OK;
 }
