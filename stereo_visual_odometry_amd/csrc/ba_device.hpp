@@ -22,6 +22,7 @@
 namespace hipba {
 
 constexpr int kBlock = 256;        // threads per workgroup in the observation kernels
+constexpr int kWideBlock = 1024;   // threads of a per-window kernel when the window is a lone large one
 constexpr int kPartialStride = 4;  // doubles of per-block partial results
 constexpr int kSmallMaxN = 192;    // largest reduced system solved inside one workgroup's LDS
 constexpr int kLdsSMaxCam = 21;    // most poses for which the packed reduced matrix is accumulated in LDS

@@ -160,16 +160,27 @@ hipError_t big_env_tiles(const DevP& P, const BigWork& W, int tile0, int n_tiles
 // sweep stores the canonical quiet NaN for any NaN of its own)
 constexpr unsigned long long kNotYet = 0x7ff8dead7ff8deadull;
 
-__global__ void k_pad_init(DevP P, double* A, int n, int npad, int ld, unsigned* sync, unsigned* flags, double* y_not_yet) {
+// A workgroup takes kPadCols columns and walks their rows [n, ld) with the row index fastest, so that a wave writes
+// runs of consecutive words (one thread per column wrote ld * 8 bytes apart: 34 us at 12000 columns against 8).
+constexpr int kPadCols = 16;
+__global__ __launch_bounds__(256) void k_pad_init(DevP P, double* A, int n, int npad, int ld, unsigned* sync, unsigned* flags,
+                                                  double* y_not_yet) {
   if (!P.ws[0].active) return;
-  const int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col < 3) sync[col] = 0u;  // hand-off words of this factorisation's launches (see k_update_stream)
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid < 3) sync[gid] = 0u;  // hand-off words of this factorisation's launches (see k_update_stream)
   // the tile counters of the band updates (behind one word per panel that older sweeps used)
-  if (col < 2 * (npad / NB + 1)) flags[col] = 0u;
-  if (col >= npad) return;
-  if (y_not_yet) reinterpret_cast<unsigned long long*>(y_not_yet)[col] = kNotYet;
-  for (int row = n; row < ld; ++row) A[(long long)col * ld + row] = (row == col) ? 1.0 : 0.0;
-  if (col < n) A[(long long)col * ld + npad] = P.b[6ll * P.wd[0].cam_base + col];
+  if (gid < 2 * (npad / NB + 1)) flags[gid] = 0u;
+  if (gid < npad && y_not_yet) reinterpret_cast<unsigned long long*>(y_not_yet)[gid] = kNotYet;
+  const int col0 = blockIdx.x * kPadCols;
+  const int span = ld - n;
+  const double* b = P.b + 6ll * P.wd[0].cam_base;
+  for (int idx = threadIdx.x; idx < kPadCols * span; idx += blockDim.x) {
+    const int col = col0 + idx / span, row = n + idx % span;
+    if (col >= npad) break;
+    double v = (row == col) ? 1.0 : 0.0;
+    if (row == npad && col < n) v = b[col];
+    A[(long long)col * ld + row] = v;
+  }
 }
 
 // z = row npad of the factored matrix
@@ -1051,7 +1062,7 @@ hipError_t big_solve_cholesky(const DevP& P, const BigWork& W, const int* h_firs
     return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 0;
   }();
   const bool one_launch_sweep = nt <= max_resident;  // as one launch of nt workgroups that hand y_k to each other
-  hipLaunchKernelGGL(k_pad_init, dim3((npad + 255) / 256), dim3(256), 0, s, P, W.A, n, npad, ld, W.sync, W.flags,
+  hipLaunchKernelGGL(k_pad_init, dim3((npad + kPadCols - 1) / kPadCols), dim3(256), 0, s, P, W.A, n, npad, ld, W.sync, W.flags,
                      one_launch_sweep ? W.rhs : (double*)nullptr);
   // Two-level right-looking factorisation.  Panels of 128 columns are grouped in blocks of kOuter
   // panels.  Inside a block a freshly factored panel only updates the block's remaining panel columns

@@ -1268,8 +1268,8 @@ __device__ __forceinline__ void pose_update_window(const DevP& P, int w, double*
   if (threadIdx.x == 0) { st->pose_step2 = acc[0]; st->pose_x2 = acc[1]; }
 }
 
-__global__ __launch_bounds__(kBlock) void k_pose_update(DevP P) {
-  __shared__ double red[2 * 4];
+__global__ __launch_bounds__(kWideBlock) void k_pose_update(DevP P) {
+  __shared__ double red[2 * (kWideBlock / 64)];
   const WinState* st = P.ws + blockIdx.x;
   if (!st->active || st->solve_failed) return;
   pose_update_window(P, blockIdx.x, red);
@@ -1362,8 +1362,9 @@ __device__ void window_gradient_check(const DevP& P, const LmParams& lm, const W
   if (mode != kDecide) {
 #pragma unroll 8
     for (int b = wd.pm_blk_begin + threadIdx.x; b < wd.pm_blk_end; b += blockDim.x) {
-      gm = fmax(gm, P.gpart[2ll * b]);
-      g2[0] += P.gpart[2ll * b + 1];
+      const double2 gp = reinterpret_cast<const double2*>(P.gpart)[b];  // (max, sum of squares) of block b
+      gm = fmax(gm, gp.x);
+      g2[0] += gp.y;
     }
     gm = block_max(gm, red);
     block_sum<1>(g2, red);
@@ -1401,7 +1402,7 @@ __device__ void window_gradient_check(const DevP& P, const LmParams& lm, const W
 // end of an iteration: reduce the per-block partials and run Ceres' acceptance logic
 // (TrustRegionMinimizer::Minimize, LevenbergMarquardtStrategy::StepAccepted/Rejected/IsInvalid)
 __device__ __forceinline__ void window_control_body(const DevP& P, const LmParams& lm, int mode) {
-  __shared__ double red[5 * 4];
+  __shared__ double red[5 * (kWideBlock / 64)];
   const int w = blockIdx.x;
   WinState* st = P.ws + w;
   if (!st->active) return;
@@ -1415,12 +1416,14 @@ __device__ __forceinline__ void window_control_body(const DevP& P, const LmParam
     const double* p2 = P.partial + nb * kPartialStride;  // second bank: candidate cost
     // (unrolled: a large window has tens of thousands of blocks, and the loads of one trip do not depend on the last)
 #pragma unroll 8
-    for (int b = wd.pm_blk_begin + threadIdx.x; b < wd.pm_blk_end; b += kBlock) {
-      const double* pr = P.partial + (long long)b * kPartialStride;
-      acc[0] += pr[0]; acc[1] += pr[1]; acc[2] += pr[2];
-      acc[3] += p2[(long long)b * kPartialStride]; acc[4] += p2[(long long)b * kPartialStride + 1];
+    for (int b = wd.pm_blk_begin + threadIdx.x; b < wd.pm_blk_end; b += blockDim.x) {
+      const double2* pr = reinterpret_cast<const double2*>(P.partial + (long long)b * kPartialStride);
+      const double2 pa = pr[0], pb = pr[1];
+      const double2 pc = *reinterpret_cast<const double2*>(p2 + (long long)b * kPartialStride);
+      acc[0] += pa.x; acc[1] += pa.y; acc[2] += pb.x;
+      acc[3] += pc.x; acc[4] += pc.y;
     }
-    for (int b = wd.vc_blk_begin + threadIdx.x; b < wd.vc_blk_end; b += kBlock) {
+    for (int b = wd.vc_blk_begin + threadIdx.x; b < wd.vc_blk_end; b += blockDim.x) {
       const double* pr = P.partial + (long long)b * kPartialStride;
       acc[0] += pr[0];
       acc[3] += p2[(long long)b * kPartialStride]; acc[4] += p2[(long long)b * kPartialStride + 1];
@@ -1517,7 +1520,7 @@ __device__ __forceinline__ void window_control_body(const DevP& P, const LmParam
 // launch of k_count_active
 // zero_S: a window that goes on to another iteration has its packed reduced matrix zeroed here, so the host does
 // not queue a memset (a launch of its own on the iteration's critical path) before every pass
-__global__ __launch_bounds__(kBlock) void k_window_control(DevP P, LmParams lm, int mode, int* count_out, int zero_S) {
+__global__ __launch_bounds__(kWideBlock) void k_window_control(DevP P, LmParams lm, int mode, int* count_out, int zero_S) {
   window_control_body(P, lm, mode);
   if (count_out && threadIdx.x == 0) *count_out = P.ws[blockIdx.x].active ? 1 : 0;
   if (!zero_S) return;
@@ -1527,7 +1530,7 @@ __global__ __launch_bounds__(kBlock) void k_window_control(DevP P, LmParams lm, 
   const WinDesc wd = P.wd[blockIdx.x];
   double2* Sw = reinterpret_cast<double2*>(P.S + wd.S_off);
   const long long n2 = 18ll * ((long long)wd.ncam * (wd.ncam + 1) / 2);
-  for (long long i = threadIdx.x; i < n2; i += kBlock) Sw[i] = make_double2(0.0, 0.0);
+  for (long long i = threadIdx.x; i < n2; i += blockDim.x) Sw[i] = make_double2(0.0, 0.0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2051,8 +2054,8 @@ __global__ __launch_bounds__(kSolveThreads) void k_window_solve_tiles(DevP P, Lm
 }
 
 // gradient check alone, for windows whose reduced system is solved by the large-matrix path
-__global__ __launch_bounds__(kBlock) void k_window_gradient(DevP P, LmParams lm, int mode) {
-  __shared__ double red[8];
+__global__ __launch_bounds__(kWideBlock) void k_window_gradient(DevP P, LmParams lm, int mode) {
+  __shared__ double red[kWideBlock / 64];
   const int w = blockIdx.x;
   WinState* st = P.ws + w;
   if (!st->active) return;
@@ -2257,8 +2260,15 @@ hipError_t launch_window_solve_small(const DevP& P, const LmParams& lm, int max_
   return hipGetLastError();
 }
 
+// Workgroup size of the one-workgroup-per-window kernels (gradient norms, candidate poses, step control): a lone large
+// window has tens of thousands of per-block partial sums and thousands of poses behind one workgroup, so it gets 16
+// waves instead of 4.  Batches and small windows keep 4, and with them the order of their sums.
+static unsigned window_threads(const DevP& P) {
+  return (P.n_windows == 1 && (long long)P.n_blk_pm + P.n_blk_vc >= 2048) ? kWideBlock : kBlock;
+}
+
 hipError_t launch_window_gradient(const DevP& P, const LmParams& lm, int mode, hipStream_t s) {
-  hipLaunchKernelGGL(k_window_gradient, dim3(P.n_windows), dim3(kBlock), 0, s, P, lm, mode);
+  hipLaunchKernelGGL(k_window_gradient, dim3(P.n_windows), dim3(window_threads(P)), 0, s, P, lm, mode);
   return hipGetLastError();
 }
 
@@ -2279,7 +2289,7 @@ hipError_t launch_backsub(const DevP& P, const LmParams& lm, bool with_cost, hip
 }
 
 hipError_t launch_pose_update(const DevP& P, hipStream_t s) {
-  hipLaunchKernelGGL(k_pose_update, dim3(P.n_windows), dim3(kBlock), 0, s, P);
+  hipLaunchKernelGGL(k_pose_update, dim3(P.n_windows), dim3(window_threads(P)), 0, s, P);
   return hipGetLastError();
 }
 
@@ -2289,7 +2299,7 @@ hipError_t launch_window_init(const DevP& P, const LmParams& lm, int mode, hipSt
 }
 
 hipError_t launch_window_control(const DevP& P, const LmParams& lm, int mode, int* count_out, int zero_S, hipStream_t s) {
-  hipLaunchKernelGGL(k_window_control, dim3(P.n_windows), dim3(kBlock), 0, s, P, lm, mode, count_out, zero_S);
+  hipLaunchKernelGGL(k_window_control, dim3(P.n_windows), dim3(window_threads(P)), 0, s, P, lm, mode, count_out, zero_S);
   return hipGetLastError();
 }
 
