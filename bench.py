@@ -137,13 +137,15 @@ def oracle_problem(oracle, p):
                           p.point_const)
 
 
-def cpu_baseline(threads, solver=None):
-    """The CPU oracle (restated Ceres path: numeric central-difference Jacobians, exact solve) on a
-    1/4-scale sample of the workload, same scene generator and starting noise -- and, for a like-for-like ratio, the
-    engine on that same sample."""
+def cpu_baseline(threads, solver=None, full_prob=None, engine_log=None, budget_s=120.0):
+    """The CPU oracle (restated Ceres path: numeric central-difference Jacobians as the reference differentiates, exact
+    solve) on the host cores.  First on a 1/4-scale sample of the workload (same scene generator, same starting noise),
+    with the engine on that same sample beside it; then, if the quarter-scale timing says it fits the budget, on the
+    quoted configuration itself for two LM iterations -- that run is the headline baseline, and its first costs are
+    set beside the engine's log of the same steps."""
     from oracle import oracle
     from stereo_visual_odometry_amd import hipba, scenes
-    prob, _, _ = scenes.bal_scale_hard(seed=3000, grid=(20, 25), n_points=250_000)
+    prob, _, _ = scenes.bal_scale_bench(grid=(20, 25), n_points=250_000)
     o = oracle_problem(oracle, prob)
     iters = 4
     opts = oracle.default_options(max_num_iterations=iters, num_threads=threads)
@@ -151,12 +153,11 @@ def cpu_baseline(threads, solver=None):
     s, its = oracle.solve(o, opts)
     dt = time.time() - t0
     done = max(len(its) - 1, 1)
-    out = {
+    quarter = {
         "value": done / dt, "unit": "LM iterations/s", "cores": threads, "kind": "port",
         "sample": "restated-Ceres oracle (numeric central-difference Jacobians, exact Schur+Cholesky solve), "
                   "%d LM iterations on a 1/4-scale problem from the same generator and start: 500 cameras x 250k landmarks "
-                  "x 2M observations (evaluate %.2fs, linear solve %.2fs); the full-size problem has 4x the observations "
-                  "and a 64x larger dense factorisation" % (done, s["time_evaluate_s"], s["time_linear_solve_s"]),
+                  "x 2M observations (evaluate %.2fs, linear solve %.2fs)" % (done, s["time_evaluate_s"], s["time_linear_solve_s"]),
     }
     if solver is not None:
         dp = solver.upload(prob)
@@ -165,10 +166,36 @@ def cpu_baseline(threads, solver=None):
         dp.reset()
         gs = dp.solve(go)[0]
         dp.free()
-        # (the two do not end on the same cost: from this start the reference's numeric differentiation and the
-        # engine's closed-form Jacobians already part ways in the first step)
-        out["engine_on_same_sample"] = {"value": max(gs["num_linear_solves"], 1) / gs["time_solve_s"],
-                                        "unit": "LM iterations/s", "lm_iterations": gs["num_linear_solves"]}
+        quarter["engine_on_same_sample"] = {"value": max(gs["num_linear_solves"], 1) / gs["time_solve_s"],
+                                            "unit": "LM iterations/s", "lm_iterations": gs["num_linear_solves"]}
+    if full_prob is None:
+        return quarter
+    # the quoted configuration: 4x the observations (evaluation, elimination) and a 64x larger dense factorisation
+    full_iters = 2
+    estimate = full_iters * (4.0 * s["time_evaluate_s"] + 64.0 * s["time_linear_solve_s"]) / done
+    if estimate > budget_s:
+        quarter["full_size_skipped"] = ("estimated %.0f s for %d LM iterations of the oracle on the full problem "
+                                        "(budget %.0f s)" % (estimate, full_iters, budget_s))
+        return quarter
+    of = oracle_problem(oracle, full_prob)
+    t0 = time.time()
+    sf, fits = oracle.solve(of, oracle.default_options(max_num_iterations=full_iters, num_threads=threads))
+    dtf = time.time() - t0
+    donef = max(len(fits) - 1, 1)
+    n_c, n_p, n_o = full_prob.poses.shape[0], full_prob.points.shape[0], full_prob.obs_pose.shape[0]
+    out = {
+        "value": donef / dtf, "unit": "LM iterations/s", "cores": threads, "kind": "port",
+        "sample": "restated-Ceres oracle (numeric central-difference Jacobians, exact Schur+Cholesky solve), %d LM "
+                  "iterations on the quoted configuration itself, %d cameras x %d landmarks x %d observations, same start "
+                  "(evaluate %.1fs, linear solve %.1fs)" % (donef, n_c, n_p, n_o, sf["time_evaluate_s"], sf["time_linear_solve_s"]),
+        "costs": [it["cost"] for it in fits],
+        "quarter_scale": quarter,
+    }
+    if engine_log:
+        # the engine's closed-form Jacobians against the reference's numeric differentiation, step by step
+        eng = [it["cost"] for it in engine_log[:len(fits)]]
+        out["engine_costs_same_steps"] = eng
+        out["max_relative_cost_difference"] = max(abs(a - b) / abs(b) for a, b in zip(eng, out["costs"]))
     return out
 
 
@@ -378,6 +405,24 @@ def replica_windows(solver, rank, world, fence, n_w=1024):
     return n_w, sum(r["num_iterations"] - 1 for r in res), dt
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` started plainly: run the same command line as N ranks of one node under
+    torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1 at a free port) as a CHILD process.
+    Called before anything in this process has touched the GPU; returns the child's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if env.get("HIPBA_BENCH_ONE_DEVICE") == "1":
+        env.setdefault("HIPBA_COMM_HOST_SYNC", "1")  # every rank on device 0 through gloo: see TorchComm
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -389,6 +434,12 @@ def main():
     ap.add_argument("--linear-solver", default="cholesky", choices=["cholesky", "pcg"])
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started plainly with --gpus N: launch the N ranks as a child job (one process per GPU) and pass its
+        # output and exit code on.  This process has not touched the GPU (torch is not even imported yet) and
+        # never will: it only waits for the child.
+        sys.exit(launch_ranks(args.gpus))
+
     import torch
     import torch.distributed as dist
     from stereo_visual_odometry_amd import hipba, scenes
@@ -396,9 +447,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
+    if args.gpus != world and rank == 0:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d: running with %d ranks" % (args.gpus, world, world), file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
     # rehearsal on a one-GPU box: every rank on device 0, collectives through gloo (everything but RCCL itself)
@@ -415,7 +465,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     solver = hipba.Solver(local_rank)
-    prob, _, _ = scenes.bal_scale_hard(seed=3000, n_points=args.points)
+    prob, _, _ = scenes.bal_scale_bench(seed=3000, n_points=args.points)
     n_c, n_p, n_o = prob.poses.shape[0], prob.points.shape[0], prob.obs_pose.shape[0]
     lin = hipba.LINEAR_DENSE_CHOLESKY if args.linear_solver == "cholesky" else hipba.LINEAR_PCG
 
@@ -489,7 +539,7 @@ def main():
                                    "landmark-aligned observation shards over %d GPU(s), reduced camera system by %s; "
                                    "start %.1f m / %.2f rad / %.1f m from the truth, Ceres default tolerances"
                                    % (n_c, n_p, n_o, world, "fp64 matrix-core Cholesky" if lin == 1 else "block-Jacobi PCG",
-                                      scenes.HARD_START["sigma_t"], scenes.HARD_START["sigma_w"], scenes.HARD_START["sigma_p"]),
+                                      scenes.BENCH_START["sigma_t"], scenes.BENCH_START["sigma_w"], scenes.BENCH_START["sigma_p"]),
                        "cameras": n_c, "landmarks": n_p, "observations": n_o, "linear_solver": args.linear_solver,
                        "termination_type": TERMINATION[summary["termination_type"]],
                        "num_successful_steps": summary["num_successful_steps"] - 1,  # Ceres counts iteration 0 too
@@ -502,6 +552,9 @@ def main():
         if world > 1:
             result["allreduce_calls_per_step"] = comm.calls / max(steps_done + args.warmup, 1)
             result["allreduce_bytes_per_step"] = comm.bytes / max(steps_done + args.warmup, 1)
+            result["collective"] = ("gloo through torch.distributed, every rank on device 0 (rehearsal)" if rehearsal
+                                    else "ncclAllReduce (RCCL) issued by the engine on its own streams")
+            result["collective_ranks"] = world
     if world > 1:
         dist.barrier()
         if not args.no_secondary:
@@ -525,7 +578,12 @@ def main():
             dp.free()
             result["secondary"] = secondary_measurements(solver, not args.no_cpu_baseline, threads)
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(threads, solver)
+            # (the engine's log of the first steps, for the step-by-step comparison with the oracle at full size)
+            dp2 = solver.upload(prob)
+            first = dp2.solve(lm_options(2), log=True)[0]["iterations"]
+            dp2.free()
+            full = prob if args.points == 1_000_000 else None
+            result["cpu_baseline"] = cpu_baseline(threads, solver, full, first)
         print(json.dumps(result))
     if world > 1:
         dist.barrier()

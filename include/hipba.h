@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 /* bumped whenever a struct of this header changes size or layout; hipba_version() returns the library's value */
-#define HIPBA_VERSION 102
+#define HIPBA_VERSION 103
 
 /* status codes */
 enum {
@@ -293,6 +293,15 @@ int hipba_download(hipba_handle h, hipba_device_problem dp, int32_t window, doub
                    double* points);
 int hipba_free_problem(hipba_handle h, hipba_device_problem dp);
 
+/*
+ * The pose parameterisation's Plus on n poses at once: out[i] = poses[i] * exp(deltas[i]), what
+ * Sophus::Manifold<Sophus::SE3>::Plus does for the blocks added at src/solve/optimizer.cpp:17,27 (tangent order
+ * upsilon then omega; small-angle series below |omega| = 1e-10; Sophus' first-order renormalisation of the product's
+ * quaternion).  HOST arrays: poses [7 n], deltas [6 n], out [7 n]; computed on the device by the same function the
+ * solver's pose update calls.
+ */
+int hipba_se3_plus(hipba_handle h, int64_t n, const double* poses, const double* deltas, double* out);
+
 /* ---- the steps either side of bundle adjustment in the per-frame pipeline ------------------- */
 /*
  * Linear triangulation of stereo matches, what Triangulator::triangulate does for every keyframe
@@ -333,7 +342,11 @@ int hipba_refine_pose(hipba_handle h, double fx, double fy, double cx, double cy
  * The hypothesis with the most matches inside reprojection_error wins (the lowest number among equals), `inliers`
  * ([n] bytes, may be NULL) marks them, *n_inliers counts them; with refine != 0 the pose is then refined on them
  * (hipba_refine_pose).  The sampling is a counter-based generator: the same seed gives the same hypotheses on any
- * machine.  HIPBA_ERR_INVALID_ARGUMENT with fewer than 4 matches.
+ * machine.  A match counts as an inlier when its squared reprojection error is <= reprojection_error^2 (OpenCV's
+ * test).  When no hypothesis gathers at least four inliers, or the winner is not finite, the call does what
+ * cv::solvePnPRansac does when it returns false: pose is left as it came in, the mask is cleared and *n_inliers = 0
+ * (the status is still HIPBA_OK: test *n_inliers).  Not result-identical to OpenCV: other samples, another minimal
+ * solver, no early stop.  HIPBA_ERR_INVALID_ARGUMENT with fewer than 4 matches.
  */
 int hipba_pnp_ransac(hipba_handle h, double fx, double fy, double cx, double cy, int32_t camera_model, int64_t n,
                      const double* points, const double* uv, double pose[7], int32_t iterations,
@@ -366,16 +379,16 @@ enum {
   HIPBA_KERNEL_COUNT = 6
 };
 /*
- * Launches one hot-path kernel `repeats` times on the resident problem's current
- * state and returns the average duration of one launch in milliseconds measured
- * with HIP events on the handle's stream.  Does not change the parameters.
- */
-/*
  * Floating-point operations of one Cholesky factorisation of the resident problem's largest reduced camera
  * system: as a dense matrix ((6 n_c)^3 / 3), and inside the envelope the library's pose order leaves (what the
  * factorisation actually has to do; equal to the dense figure for windows solved in LDS or without an envelope).
  */
 int hipba_reduced_solve_flops(hipba_device_problem dp, double* flops_dense, double* flops_envelope);
+/*
+ * Launches one hot-path kernel `repeats` times on the resident problem's current
+ * state and returns the average duration of one launch in milliseconds measured
+ * with HIP events on the handle's stream.  Does not change the parameters.
+ */
 int hipba_time_kernel(hipba_handle h, hipba_device_problem dp, const hipba_options* options,
                       int32_t kernel, int32_t repeats, double* avg_ms);
 

@@ -390,7 +390,10 @@ static int chol_unblocked(double* A, int64_t lda, int n) {
   return 0;
 }
 
+static int chol_factor_tiled(double* A, int n, int num_threads);
+
 static int chol_factor(double* A, int n, int num_threads) {
+  if (n >= 1536) return chol_factor_tiled(A, n, num_threads);
   const int nb = 64;
   const int64_t lda = n;
   for (int k = 0; k < n; k += nb) {
@@ -419,6 +422,95 @@ static int chol_factor(double* A, int n, int num_threads) {
         for (int t = 0; t < kb; ++t) s += li[t] * lj[t];
         A[i * lda + j] -= s;
       }
+    }
+  }
+  return 0;
+}
+
+/* Large matrices (the reduced camera system of thousands of poses): the same right-looking factorisation with
+ * the trailing update done on cache-sized tiles by a 4x4 register kernel, four partial sums per entry (t mod 4),
+ * so that a full-size CPU baseline finishes in seconds.  Same arithmetic up to the order of the additions. */
+typedef double v4d __attribute__((vector_size(32)));
+typedef double v4d_unaligned __attribute__((vector_size(32), aligned(8)));
+#define ld4(p) ((v4d)(*(const v4d_unaligned*)(p)))
+
+/* A[i][j] -= sum_t A[i][k0+t] A[j][k0+t]  for i in [i0,i1), j in [j0, min(j1, i+1)) */
+__attribute__((target_clones("avx2", "default")))
+void oracle_syrk_tile(double* A, int64_t lda, int k0, int kb, int i0, int i1, int j0, int j1) {
+  const int kb4 = kb & ~3;
+  for (int i = i0; i < i1; i += 4) {
+    const int ih = (i + 4 <= i1) ? 4 : i1 - i;
+    int j = j0;
+    if (ih == 4) {
+      for (; j + 4 <= j1 && j + 3 <= i; j += 4) {
+        const double* a0 = A + (int64_t)i * lda + k0;
+        const double* b0 = A + (int64_t)j * lda + k0;
+        v4d acc[4][4];
+        for (int p = 0; p < 4; ++p)
+          for (int q = 0; q < 4; ++q) acc[p][q] = (v4d){0.0, 0.0, 0.0, 0.0};
+        for (int t = 0; t < kb4; t += 4) {
+          const v4d x0 = ld4(a0 + t), x1 = ld4(a0 + lda + t), x2 = ld4(a0 + 2 * lda + t), x3 = ld4(a0 + 3 * lda + t);
+          const v4d y0 = ld4(b0 + t), y1 = ld4(b0 + lda + t), y2 = ld4(b0 + 2 * lda + t), y3 = ld4(b0 + 3 * lda + t);
+          acc[0][0] += x0 * y0; acc[0][1] += x0 * y1; acc[0][2] += x0 * y2; acc[0][3] += x0 * y3;
+          acc[1][0] += x1 * y0; acc[1][1] += x1 * y1; acc[1][2] += x1 * y2; acc[1][3] += x1 * y3;
+          acc[2][0] += x2 * y0; acc[2][1] += x2 * y1; acc[2][2] += x2 * y2; acc[2][3] += x2 * y3;
+          acc[3][0] += x3 * y0; acc[3][1] += x3 * y1; acc[3][2] += x3 * y2; acc[3][3] += x3 * y3;
+        }
+        for (int p = 0; p < 4; ++p)
+          for (int q = 0; q < 4; ++q) {
+            double sum = (acc[p][q][0] + acc[p][q][1]) + (acc[p][q][2] + acc[p][q][3]);
+            for (int t = kb4; t < kb; ++t) sum += a0[p * lda + t] * b0[q * lda + t];
+            A[(int64_t)(i + p) * lda + j + q] -= sum;
+          }
+      }
+    }
+    /* what the 4x4 kernel leaves: the blocks the diagonal crosses and ragged edges */
+    for (int p = 0; p < ih; ++p) {
+      const double* a0 = A + (int64_t)(i + p) * lda + k0;
+      const int jend = (j1 < i + p + 1) ? j1 : i + p + 1;
+      for (int jj = j; jj < jend; ++jj) {
+        const double* b0 = A + (int64_t)jj * lda + k0;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        for (int t = 0; t < kb4; t += 4) {
+          s0 += a0[t] * b0[t]; s1 += a0[t + 1] * b0[t + 1]; s2 += a0[t + 2] * b0[t + 2]; s3 += a0[t + 3] * b0[t + 3];
+        }
+        double sum = (s0 + s1) + (s2 + s3);
+        for (int t = kb4; t < kb; ++t) sum += a0[t] * b0[t];
+        A[(int64_t)(i + p) * lda + jj] -= sum;
+      }
+    }
+  }
+}
+
+static int chol_factor_tiled(double* A, int n, int num_threads) {
+  const int nb = 128, tile = 192;
+  const int64_t lda = n;
+  for (int k = 0; k < n; k += nb) {
+    const int kb = (n - k < nb) ? n - k : nb;
+    if (chol_unblocked(A + k * lda + k, lda, kb)) return 1;
+    const int r0 = k + kb;
+    if (r0 >= n) break;
+#pragma omp parallel for num_threads(num_threads) schedule(static)
+    for (int i = r0; i < n; ++i) {
+      double* row = A + i * lda + k;
+      for (int j = 0; j < kb; ++j) {
+        double s = row[j];
+        const double* lj = A + (k + j) * lda + k;
+        for (int t = 0; t < j; ++t) s -= row[t] * lj[t];
+        row[j] = s / lj[j];
+      }
+    }
+    const int nt = (n - r0 + tile - 1) / tile;
+    const int n_tiles = nt * (nt + 1) / 2;
+#pragma omp parallel for num_threads(num_threads) schedule(dynamic, 1)
+    for (int idx = 0; idx < n_tiles; ++idx) {
+      /* idx -> (ti, tj), tj <= ti, rows of large ti first so that the long rows are not left for last */
+      int ti = nt - 1, rem = idx;
+      while (rem > ti) { rem -= ti + 1; --ti; }
+      const int tj = rem;
+      const int i0 = r0 + ti * tile, j0 = r0 + tj * tile;
+      const int i1 = (i0 + tile < n) ? i0 + tile : n, j1 = (j0 + tile < n) ? j0 + tile : n;
+      oracle_syrk_tile(A, lda, k, kb, i0, i1, j0, j1);
     }
   }
   return 0;
@@ -687,13 +779,20 @@ static int solve_schur(prog* g, const double* D, double* y) {
     }
     free(fill);
   }
+  /* Every thread walks all landmarks and forms the products whose ROW block falls into its own range of poses:
+   * one writer per word of S and b, and per word the same order of additions whatever the thread count. */
+  const int n_workers = (g->O->num_threads > 1 && npt > 50000) ? g->O->num_threads : 1;
+#pragma omp parallel for num_threads(n_workers) schedule(static, 1)
+  for (int worker = 0; worker < n_workers; ++worker) {
+  const int own_lo = poff + 6 * (int)(((int64_t)g->n_ap * worker) / n_workers);
+  const int own_hi = poff + 6 * (int)(((int64_t)g->n_ap * (worker + 1)) / n_workers);
   for (int q = 0; q < npt; ++q) {
     const double* Vi = V + 9 * q;
     const int64_t s0 = start[q], s1 = start[q + 1];
     for (int64_t ii = s0; ii < s1; ++ii) {
       const int64_t a = order[ii];
       const int pci = g->pose_col[P->obs_pose[g->act[a]]];
-      if (pci < 0) continue;
+      if (pci < own_lo || pci >= own_hi) continue;  /* (a constant pose has column -1) */
       const double* Jc = g->Jc + 12 * a;
       const double* Jp = g->Jp + 6 * a;
       double W[18], Y[18]; /* W = Jc^T Jp (6x3), Y = W V^-1 */
@@ -722,6 +821,7 @@ static int solve_schur(prog* g, const double* D, double* y) {
           }
       }
     }
+  }
   }
   int rc = 0;
   if (nc > 0) {

@@ -305,9 +305,9 @@ def pnp_ransac(K, points, uv, prior, iterations=1000, reprojection_error=3.0, se
                 break
         everything.poses[0] = pose
         res = evaluate(everything, JAC_ANALYTIC, apply_loss=False)["residuals"]
-        counts[h] = int(((res * res).sum(axis=1) < thr2).sum())
+        counts[h] = int(((res * res).sum(axis=1) <= thr2).sum())
         poses[h] = pose
     best = int(np.argmax(counts))  # the first of equals
     everything.poses[0] = poses[best]
     res = evaluate(everything, JAC_ANALYTIC, apply_loss=False)["residuals"]
-    return poses[best].copy(), ((res * res).sum(axis=1) < thr2).astype(np.uint8), counts
+    return poses[best].copy(), ((res * res).sum(axis=1) <= thr2).astype(np.uint8), counts

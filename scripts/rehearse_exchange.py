@@ -23,7 +23,7 @@ def timed(dp, opts, comm=None):
 def main():
     n_points = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
     grid = (40, 50) if n_points >= 500_000 else (20, 25)
-    prob, _, _ = scenes.bal_scale_hard(n_points=n_points, grid=grid)
+    prob, _, _ = scenes.bal_scale_bench(n_points=n_points, grid=grid)
     sv = hipba.Solver(0)
     opts = hipba.default_options(max_num_iterations=10, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
     dp = sv.upload(prob)

@@ -7,7 +7,7 @@ from stereo_visual_odometry_amd import hipba, scenes
 n_points = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 rep = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 solver = hipba.Solver(0)
-prob, _, _ = scenes.bal_scale_hard(seed=3000, n_points=n_points)
+prob, _, _ = scenes.bal_scale_bench(seed=3000, n_points=n_points)
 dp = solver.upload(prob)
 o = hipba.default_options(max_num_iterations=4)
 for k in range(6):

@@ -89,6 +89,8 @@ struct WinState {
   int last_success_log; // log entry whose gradient norms are filled by the next linearisation
   int lin_iters;
   int num_linear_solves; // trust-region steps computed, the one a convergence test ends on included
+  int handoff_timeouts;  // sticky: a bounded wait between workgroups of the reduced solver ran out (reported as an error)
+  int pad_;
   double radius;
   double decrease_factor;
   double x_cost;

@@ -814,7 +814,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     *ok = good;
-    if (!good) P.ws[0].solve_failed = 1;  // never seen: the launch's other workgroups always run
+    if (!good) { P.ws[0].solve_failed = 1; P.ws[0].handoff_timeouts = 1; }  // never seen: the launch's other workgroups always run
   }
   __syncthreads();
   const int good = *ok;
@@ -988,7 +988,7 @@ __global__ __launch_bounds__(kTrsvThreads) void k_trsv_pipeline(DevP P, const do
 #undef TRSV_LINV_LOAD
   __syncthreads();
   if (!s_ok) {  // never seen: a producer of this launch did not arrive
-    if (t == 0) P.ws[0].solve_failed = 1;
+    if (t == 0) { P.ws[0].solve_failed = 1; P.ws[0].handoff_timeouts = 1; }
     return;
   }
   {
@@ -1056,11 +1056,15 @@ hipError_t big_solve_cholesky(const DevP& P, const BigWork& W, const int* h_firs
   const int* d_first = h_first ? W.first : nullptr;
   if (!P.dense_S)  // otherwise the elimination has written the blocks where they belong
     hipLaunchKernelGGL(k_unpack_lower, dim3((ncam * 36 + 255) / 256, ncam), dim3(256), 0, s, P, W.A, ld);
-  static const int max_resident = [] {
-    hipDeviceProp_t prop;
+  // compute units of the device this solve runs on (the stream's: the current one); asked per call, handles of
+  // one process may sit on different devices
+  int max_resident = 0;
+  {
     int dev = 0;
-    return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 0;
-  }();
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&max_resident, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      max_resident = 0;
+  }
   const bool one_launch_sweep = nt <= max_resident;  // as one launch of nt workgroups that hand y_k to each other
   hipLaunchKernelGGL(k_pad_init, dim3((npad + kPadCols - 1) / kPadCols), dim3(256), 0, s, P, W.A, n, npad, ld, W.sync, W.flags,
                      one_launch_sweep ? W.rhs : (double*)nullptr);

@@ -175,6 +175,7 @@ struct hipba_handle_s {
   hipStream_t xchg_stream = nullptr;
   hipEvent_t xchg_packed = nullptr;
   hipEvent_t xchg_ready[kMaxFeedChunks] = {};
+  bool xchg_ready_all = false;  // the stream and every event above exist
 };
 
 struct WinMeta {
@@ -1169,10 +1170,13 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
             col = end;
           }
           feed.tile_begin[feed.n_chunks] = n_env_tiles;
-          if (!h->xchg_stream) {
-            HIPBA_HIP(hipStreamCreateWithFlags(&h->xchg_stream, hipStreamNonBlocking));
-            HIPBA_HIP(hipEventCreateWithFlags(&h->xchg_packed, hipEventDisableTiming));
-            for (auto& ev : h->xchg_ready) HIPBA_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+          if (!h->xchg_ready_all) {
+            // (created piece by piece; a failure part-way leaves what exists to hipba_destroy and is retried here)
+            if (!h->xchg_stream) HIPBA_HIP(hipStreamCreateWithFlags(&h->xchg_stream, hipStreamNonBlocking));
+            if (!h->xchg_packed) HIPBA_HIP(hipEventCreateWithFlags(&h->xchg_packed, hipEventDisableTiming));
+            for (auto& ev : h->xchg_ready)
+              if (!ev) HIPBA_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            h->xchg_ready_all = true;
           }
           for (int c = 0; c < feed.n_chunks; ++c) feed.ready[c] = h->xchg_ready[c];
         }
@@ -1203,7 +1207,8 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
   const bool timing = o.report_time_breakdown != 0;
   if (timing && !h->phase_ev_ready) {
     for (auto& slot_ev : h->phase_ev)
-      for (auto& ev : slot_ev) HIPBA_HIP(hipEventCreate(&ev));
+      for (auto& ev : slot_ev)
+        if (!ev) HIPBA_HIP(hipEventCreate(&ev));
     h->phase_ev_ready = true;
   }
   double t_res = 0.0, t_jac = 0.0, t_lin = 0.0;
@@ -1263,8 +1268,12 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
         for (int c = 0; c < feed.n_chunks; ++c) {
           const size_t t0 = (size_t)feed.tile_begin[c], t1 = (size_t)feed.tile_begin[c + 1];
           if (comm->allreduce(comm->ctx, P.S + t0 * kCholNB * kCholNB, (t1 - t0) * kCholNB * kCholNB, HIPBA_REDUCE_SUM,
-                              (void*)h->xchg_stream))
+                              (void*)h->xchg_stream)) {
+            // the chunks already queued on the exchange stream still read the packed matrix: let them finish before
+            // the caller gets its buffers back
+            (void)hipStreamSynchronize(h->xchg_stream);
             return fail(HIPBA_ERR_COMM, "all-reduce callback failed");
+          }
           HIPBA_HIP(hipEventRecord(feed.ready[c], h->xchg_stream));
         }
       }
@@ -1365,6 +1374,10 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
     HIPBA_HIP(hipMemcpy(log.data(), P.log, sizeof(hipba_iteration) * log.size(), hipMemcpyDeviceToHost));
     R->d2h_bytes += (long long)(sizeof(hipba_iteration) * log.size());
   }
+  for (int w = 0; w < P.n_windows; ++w)
+    if (ws[w].handoff_timeouts)
+      return fail(HIPBA_ERR_INTERNAL, "reduced solve: a hand-off between workgroups timed out (window %d); the device "
+                                      "was too busy for the one-launch pipeline -- the result is not reported", w);
   for (int w = 0; w < P.n_windows; ++w) {
     hipba_summary& sm = summaries[w];
     hipba_iteration* user_log = sm.iteration_log;
@@ -1397,8 +1410,9 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
     sm.bytes_host_to_device = 0;
     sm.bytes_device_to_host = R->d2h_bytes + 4ll * sm.num_linear_solves;  // + the 4-byte activity poll of every pass
     if (user_log && !log.empty()) {
+      // (a capacity of zero or less copies nothing)
       const int n = std::min(std::min(sm.num_iterations, user_cap), P.log_cap);
-      memcpy(user_log, log.data() + (size_t)w * P.log_cap, sizeof(hipba_iteration) * n);
+      if (n > 0) memcpy(user_log, log.data() + (size_t)w * P.log_cap, sizeof(hipba_iteration) * (size_t)n);
     }
     if (o.minimizer_progress_to_stdout && !log.empty()) {
       if (P.n_windows > 1) printf("window %d\n", w);
@@ -1542,6 +1556,8 @@ int hipba_destroy(hipba_handle h) {
     if (h->staging) (void)hipHostFree(h->staging);
     if (h->h_count) (void)hipHostFree(h->h_count);
     for (int i = 0; i < 4; ++i) if (h->poll_ev[i]) (void)hipEventDestroy(h->poll_ev[i]);
+    for (auto& slot_ev : h->phase_ev)
+      for (auto& ev : slot_ev) if (ev) (void)hipEventDestroy(ev);
     if (h->xchg_stream) (void)hipStreamSynchronize(h->xchg_stream);
     if (h->xchg_packed) (void)hipEventDestroy(h->xchg_packed);
     for (auto& ev : h->xchg_ready) if (ev) (void)hipEventDestroy(ev);
@@ -1554,10 +1570,51 @@ int hipba_destroy(hipba_handle h) {
 
 void* hipba_stream(hipba_handle h) { return h ? (void*)h->stream : nullptr; }
 
+// A window that the batched kernels cannot take (they keep every window's reduced system in LDS and every landmark
+// inside one 256-observation block): more variable poses than the in-LDS solver holds, or a landmark with more
+// observations than a block.  Judged from the caller's arrays alone, on the safe side: poses that turn out to be
+// unobserved still count.  Malformed input is left to validate_problem.
+static bool window_needs_the_large_solver(const hipba_problem& p) {
+  if (p.n_poses <= 0 || p.n_obs <= 0 || !p.obs_point || p.n_points <= 0) return false;
+  int variable = 0;
+  for (int i = 0; i < p.n_poses; ++i) variable += (p.pose_const && p.pose_const[i]) ? 0 : 1;
+  if (6 * variable > kSmallMaxN) return true;
+  if (p.n_obs <= kBlock) return false;
+  std::vector<int> degree((size_t)p.n_points, 0);
+  for (long long k = 0; k < p.n_obs; ++k) {
+    const int q = p.obs_point[k];
+    if (q < 0 || q >= p.n_points) return false;
+    if (++degree[q] > kBlock) return true;
+  }
+  return false;
+}
+
 int hipba_solve_batched(hipba_handle h, int32_t n_windows, hipba_problem* problems, const hipba_options* options,
                         hipba_summary* summaries) {
   return guarded([&]() -> int {
     if (!h || !problems || !summaries || n_windows <= 0) return fail(HIPBA_ERR_INVALID_ARGUMENT, "null argument");
+    if (n_windows > 1) {
+      // The reference sets no limit on a window (optimizer.cpp:25-51).  Windows too large for the batched kernels go
+      // through the single-window path one after another, the rest stay one batch; the results are what separate
+      // calls would give.
+      std::vector<int> large, regular;
+      for (int w = 0; w < n_windows; ++w) (window_needs_the_large_solver(problems[w]) ? large : regular).push_back(w);
+      if (!large.empty()) {
+        if (!regular.empty()) {
+          std::vector<hipba_problem> sub(regular.size());
+          std::vector<hipba_summary> sub_summary(regular.size());
+          for (size_t i = 0; i < regular.size(); ++i) { sub[i] = problems[regular[i]]; sub_summary[i] = summaries[regular[i]]; }
+          const int rc = hipba_solve_batched(h, (int32_t)regular.size(), sub.data(), options, sub_summary.data());
+          if (rc) return rc;
+          for (size_t i = 0; i < regular.size(); ++i) summaries[regular[i]] = sub_summary[i];
+        }
+        for (int w : large) {
+          const int rc = hipba_solve_batched(h, 1, problems + w, options, summaries + w);
+          if (rc) return rc;
+        }
+        return HIPBA_OK;
+      }
+    }
     hipba_options o;
     if (options) o = *options; else hipba_options_default(&o);
     HIPBA_HIP(hipSetDevice(h->device));
@@ -1884,6 +1941,32 @@ int hipba_triangulate_stereo(hipba_handle h, const double P_left[12], const doub
   });
 }
 
+int hipba_se3_plus(hipba_handle h, int64_t n, const double* poses, const double* deltas, double* out) {
+  return guarded([&]() -> int {
+    if (!h) return fail(HIPBA_ERR_INVALID_ARGUMENT, "null handle");
+    if (n < 0 || (n > 0 && (!poses || !deltas || !out))) return fail(HIPBA_ERR_INVALID_ARGUMENT, "null array");
+    if (n == 0) return HIPBA_OK;
+    HIPBA_HIP(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    const size_t pose_bytes = align_up(sizeof(double) * 7 * (size_t)n, 256), delta_bytes = align_up(sizeof(double) * 6 * (size_t)n, 256);
+    int rc = ensure_staging(h, pose_bytes + delta_bytes);
+    if (rc) return rc;
+    rc = ensure_arena(h, 2 * pose_bytes + delta_bytes);
+    if (rc) return rc;
+    char* st = static_cast<char*>(h->staging);
+    memcpy(st, poses, sizeof(double) * 7 * (size_t)n);
+    memcpy(st + pose_bytes, deltas, sizeof(double) * 6 * (size_t)n);
+    char* dv = static_cast<char*>(h->arena);
+    HIPBA_HIP(hipMemcpyAsync(dv, st, pose_bytes + delta_bytes, hipMemcpyHostToDevice, s));
+    double* d_out = reinterpret_cast<double*>(dv + pose_bytes + delta_bytes);
+    HIPBA_HIP(launch_se3_plus(n, reinterpret_cast<const double*>(dv), reinterpret_cast<const double*>(dv + pose_bytes), d_out, s));
+    HIPBA_HIP(hipMemcpyAsync(st, d_out, sizeof(double) * 7 * (size_t)n, hipMemcpyDeviceToHost, s));
+    HIPBA_HIP(hipStreamSynchronize(s));
+    memcpy(out, st, sizeof(double) * 7 * (size_t)n);
+    return HIPBA_OK;
+  });
+}
+
 int hipba_refine_pose(hipba_handle h, double fx, double fy, double cx, double cy, int32_t camera_model, int64_t n,
                       const double* points, const double* uv, const uint8_t* use, double pose[7],
                       const hipba_options* options, hipba_summary* summary) {
@@ -1957,12 +2040,21 @@ int hipba_pnp_ransac(hipba_handle h, double fx, double fy, double cx, double cy,
     HIPBA_HIP(hipMemcpyAsync(st, d_out, 256 + (size_t)n, hipMemcpyDeviceToHost, s));
     HIPBA_HIP(hipStreamSynchronize(s));
     const long long best = (long long)st[7];
+    bool finite = true;
+    for (int i = 0; i < 7; ++i) finite = finite && std::isfinite(st[i]);
+    if (best < 4 || !finite) {
+      // no hypothesis with a consensus of at least the minimal sample (cv::solvePnPRansac returns false and leaves
+      // rvec / tvec alone, estimator.cpp:28-29): the caller's pose stays, no inliers are reported
+      if (inliers) memset(inliers, 0, (size_t)n);
+      if (n_inliers) *n_inliers = 0;
+      return HIPBA_OK;
+    }
     for (int i = 0; i < 7; ++i) pose[i] = st[i];
     const unsigned char* mask = reinterpret_cast<const unsigned char*>(st) + 256;
     std::vector<uint8_t> keep(mask, mask + n);  // (the refinement below reuses the staging buffer)
     if (inliers) memcpy(inliers, keep.data(), (size_t)n);
     if (n_inliers) *n_inliers = best;
-    if (refine && best >= 3) return hipba_refine_pose(h, fx, fy, cx, cy, camera_model, n, points, uv, keep.data(), pose, nullptr, nullptr);
+    if (refine) return hipba_refine_pose(h, fx, fy, cx, cy, camera_model, n, points, uv, keep.data(), pose, nullptr, nullptr);
     return HIPBA_OK;
   });
 }

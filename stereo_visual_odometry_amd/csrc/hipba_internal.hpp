@@ -39,6 +39,9 @@ hipError_t launch_residual_jacobian(const CameraK& K, const LmParams& lm, int ap
 hipError_t launch_triangulate_stereo(const double* d_pl, const double* d_pr, long long n, const float* d_left,
                                      const float* d_right, const double* d_pose, double* d_out, hipStream_t s);
 
+// out[i] = poses[i] * exp(deltas[i]) for n poses (7 / 6 / 7 doubles each); device memory
+hipError_t launch_se3_plus(long long n, const double* d_poses, const double* d_deltas, double* d_out, hipStream_t s);
+
 // PnP hypotheses by random sample consensus: n_hyp poses from four-match samples (Gauss-Newton from d_prior), their inlier
 // counts, then d_out = the best pose [7] + its count [1] and d_mask [n]; every pointer is device memory
 hipError_t launch_pnp_ransac(const CameraK& K, long long n, const double* d_pts, const double* d_uv, const double* d_prior,

@@ -1331,6 +1331,8 @@ __global__ __launch_bounds__(kBlock) void k_window_init(DevP P, LmParams lm, int
   s.last_success_log = 0;
   s.lin_iters = 0;
   s.num_linear_solves = 0;
+  s.handoff_timeouts = 0;
+  s.pad_ = 0;
   s.radius = lm.initial_radius;
   s.decrease_factor = 2.0;
   s.x_cost = acc[0];

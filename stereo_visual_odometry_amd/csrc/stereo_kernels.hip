@@ -124,6 +124,29 @@ hipError_t launch_triangulate_stereo(const double* d_pl, const double* d_pr, lon
   return hipGetLastError();
 }
 
+// ---- the manifold's Plus on arrays of poses -------------------------------------------------------------------------
+// Sophus::Manifold<SE3>::Plus(x, delta) = x * SE3::exp(delta) (optimizer.cpp:17,27), one lane per pose: the same
+// se3_plus the solver's pose update calls, reachable on its own so that it can be checked value by value.
+__global__ __launch_bounds__(256) void k_se3_plus(long long n, const double* __restrict__ poses,
+                                                  const double* __restrict__ deltas, double* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double x[7], d[6], y[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) x[k] = poses[7 * i + k];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) d[k] = deltas[6 * i + k];
+  se3_plus(x, d, y);
+#pragma unroll
+  for (int k = 0; k < 7; ++k) out[7 * i + k] = y[k];
+}
+
+hipError_t launch_se3_plus(long long n, const double* d_poses, const double* d_deltas, double* d_out, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_se3_plus, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, d_poses, d_deltas, d_out);
+  return hipGetLastError();
+}
+
 // ---- PnP by random sample consensus (src/solve/estimator.cpp:28-29: cv::solvePnPRansac) -----------------------------
 // One lane per hypothesis: four matches drawn with a counter-based generator (the same draw for the same seed and
 // hypothesis number wherever it runs), the pose that fits them by Gauss-Newton on the reprojection error from the
@@ -222,7 +245,7 @@ __global__ __launch_bounds__(64) void k_pnp_hypotheses(CameraK K, long long n, c
   for (long long j = 0; j < n; ++j) {
     double r[2];
     residual_only(K, pose, pts + 3 * j, uv[2 * j], uv[2 * j + 1], r);
-    c += (r[0] * r[0] + r[1] * r[1] < thr2) ? 1 : 0;
+    c += (r[0] * r[0] + r[1] * r[1] <= thr2) ? 1 : 0;
   }
   count[h] = c;
 #pragma unroll
@@ -259,7 +282,7 @@ __global__ __launch_bounds__(256) void k_pnp_select(CameraK K, long long n, cons
   for (long long j = t; j < n; j += 256) {
     double r[2];
     residual_only(K, pose, pts + 3 * j, uv[2 * j], uv[2 * j + 1], r);
-    mask[j] = (r[0] * r[0] + r[1] * r[1] < thr2) ? 1 : 0;
+    mask[j] = (r[0] * r[0] + r[1] * r[1] <= thr2) ? 1 : 0;
   }
 }
 

@@ -18,7 +18,7 @@ ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_OUT_OF_MEMORY, ERR_UNSUPPORTED
     -1, -2, -3, -4, -5, -6, -7)
 EVALUATE_DEVICE_MAX_OBS = 1 << 24  # HIPBA_EVALUATE_DEVICE_MAX_OBS
 CAMERA_Z_FORWARD, CAMERA_X_FORWARD = 0, 1
-ABI_VERSION = 102  # HIPBA_VERSION of the include/hipba.h these ctypes structures mirror
+ABI_VERSION = 103  # HIPBA_VERSION of the include/hipba.h these ctypes structures mirror
 LOSS_NONE, LOSS_HUBER = 0, 1
 LINEAR_AUTO, LINEAR_DENSE_CHOLESKY, LINEAR_PCG = 0, 1, 2
 CONVERGENCE, NO_CONVERGENCE, FAILURE = 0, 1, 2
@@ -97,7 +97,7 @@ EXPORTED_SYMBOLS = [
     "hipba_solve", "hipba_solve_batched", "hipba_evaluate", "hipba_evaluate_device", "hipba_upload", "hipba_upload_shard", "hipba_pose_order", "hipba_reset", "hipba_solve_device",
     "hipba_solve_device_sharded", "hipba_download", "hipba_free_problem", "hipba_time_kernel", "hipba_reduced_solve_flops",
     "hipba_rccl_get_unique_id", "hipba_rccl_comm_create", "hipba_rccl_comm_stats", "hipba_rccl_comm_destroy",
-    "hipba_triangulate_stereo", "hipba_triangulate_stereo_device", "hipba_refine_pose", "hipba_pnp_ransac",
+    "hipba_triangulate_stereo", "hipba_triangulate_stereo_device", "hipba_refine_pose", "hipba_pnp_ransac", "hipba_se3_plus",
 ]
 
 
@@ -178,6 +178,7 @@ def load_library(path=None):
     lib.hipba_triangulate_stereo.argtypes = [C.c_void_p, _dp, _dp, C.c_int64, fp, fp, _dp, _dp]
     lib.hipba_triangulate_stereo_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                                     C.c_void_p, C.c_void_p]
+    lib.hipba_se3_plus.argtypes = [C.c_void_p, C.c_int64, _dp, _dp, _dp]
     lib.hipba_refine_pose.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int64,
                                       _dp, _dp, _bp, _dp, C.POINTER(COptions), C.POINTER(CSummary)]
     lib.hipba_pnp_ransac.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int64, _dp, _dp,
@@ -443,6 +444,17 @@ class Solver:
         """hipba_triangulate_stereo_device: device addresses (ints), queued on this handle's stream, nothing allocated."""
         _check(self._lib.hipba_triangulate_stereo_device(self._h, d_P_left, d_P_right, n, d_left_uv, d_right_uv, d_pose,
                                                          d_points))
+
+    def se3_plus(self, poses, deltas):
+        """hipba_se3_plus (Sophus::Manifold<SE3>::Plus, optimizer.cpp:17,27): poses [n,7] * exp(deltas [n,6]) -> [n,7]."""
+        x = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 7)
+        d = np.ascontiguousarray(deltas, dtype=np.float64).reshape(-1, 6)
+        if x.shape[0] != d.shape[0]:
+            raise ValueError("poses and deltas differ in length")
+        out = np.zeros_like(x)
+        _check(self._lib.hipba_se3_plus(self._h, x.shape[0], x.ctypes.data_as(_dp), d.ctypes.data_as(_dp),
+                                        out.ctypes.data_as(_dp)))
+        return out
 
     def refine_pose(self, K, points, uv, pose, use=None, camera_model=CAMERA_Z_FORWARD, options=None):
         """hipba_refine_pose (the refinement that ends cv::solvePnPRansac, estimator.cpp:28-29): (refined pose, summary)."""

@@ -175,6 +175,19 @@ def test_pnp_ransac_matches_oracle_and_finds_the_inliers(solver, oracle):
 
 
 @pytest.mark.gpu
+def test_pnp_ransac_without_a_consensus_leaves_the_pose_alone(solver):
+    """Every match a gross outlier: no hypothesis gathers the minimal sample's four inliers.  cv::solvePnPRansac
+    returns false there and the reference keeps going with what it had (estimator.cpp:28-29); the call leaves the pose
+    as it came in and reports no inliers."""
+    rng = np.random.default_rng(9)
+    pts, _, start, _, _ = scenes.pnp_case(23, n=200)
+    uv = np.stack([rng.uniform(0.0, 1241.0, 200), rng.uniform(0.0, 376.0, 200)], axis=1)
+    pose, mask = solver.pnp_ransac(scenes.KITTI_K, pts, uv, start, iterations=100, reprojection_error=0.05, seed=3)
+    np.testing.assert_array_equal(pose, start)
+    assert int(mask.sum()) == 0
+
+
+@pytest.mark.gpu
 def test_pnp_ransac_rejects_bad_arguments(solver):
     pts, uv, start, _, _ = scenes.pnp_case(22, n=10)
     with pytest.raises(hipba.HipbaError):

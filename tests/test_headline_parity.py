@@ -1,0 +1,163 @@
+"""GPU parity tests of the configurations the benchmark quotes, at (or next to) their stated sizes, every call through
+the C ABI and compared with the CPU oracle's per-iteration log:
+
+  * the BAL-scale descent bench.py times, on its quarter-scale twin (same generator, same starting noise);
+  * the envelope / pose-order path of the dense factorisation, with the natural order kept and with the reverse
+    Cuthill-McKee order taken;
+  * 1024 batched windows of 10 keyframes x 2000 landmarks in ONE hipba_solve_batched call;
+  * the SE3 manifold's Plus on the device against the oracle's, value by value;
+  * a batch that mixes windows the batched kernels can and cannot take.
+
+Tolerances (BASELINE.json north_star): cost 1e-6 relative per logged iteration, poses and landmarks 1e-6 m.
+"""
+import numpy as np
+import pytest
+
+from conftest import to_oracle
+from stereo_visual_odometry_amd import hipba, scenes
+from test_gpu_parity import ATOL_STATE, RTOL_COST, assert_logs_match, banded_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def test_benchmark_descent_matches_oracle_log_on_the_quarter_scale_twin(solver, oracle):
+    """bench.py's headline solve is scenes.bal_scale_bench (2000 cameras x 1M landmarks x 8M observations), which the
+    oracle cannot follow for a whole solve.  Its twin from the same generator and the same start, 500 cameras x 250k
+    landmarks x 2M observations, it can: ten Levenberg-Marquardt steps to convergence with Ceres' default tolerances,
+    every one of them compared (cost, trust-region radius, accept / reject) at the north star's 1e-6."""
+    prob, _, _ = scenes.bal_scale_bench(grid=(20, 25), n_points=250_000)
+    assert prob.obs_pose.shape[0] == 2_000_000 and prob.poses.shape[0] == 500
+    g = prob.copy()
+    s = solver.solve(g, hipba.default_options(max_num_iterations=40))
+    o = to_oracle(oracle, prob)
+    so, oits = oracle.solve(o, oracle.default_options(max_num_iterations=40, jacobian_mode=oracle.JAC_ANALYTIC, num_threads=16))
+    accepted = sum(1 for it in s["iterations"][1:] if it["step_is_successful"])
+    assert accepted >= 8, accepted
+    assert s["termination_type"] == so["termination_type"] == hipba.CONVERGENCE
+    assert s["num_iterations"] == so["num_iterations"]
+    assert_logs_match(s["iterations"], oits, rtol=1e-6)
+    assert abs(s["final_cost"] - so["final_cost"]) <= RTOL_COST * so["final_cost"]
+    assert s["final_cost"] < 1e-3 * s["initial_cost"]
+    assert np.abs(g.poses - o.poses).max() <= ATOL_STATE and np.abs(g.points - o.points).max() <= ATOL_STATE
+    assert s["linear_solver_used"] == hipba.LINEAR_DENSE_CHOLESKY and s["num_active_poses"] == 499
+
+
+def _shuffled_cameras(prob, seed):
+    """The same problem with its cameras renumbered at random (camera 0, the constant one, stays first)."""
+    rng = np.random.default_rng(seed)
+    perm = rng.permutation(prob.poses.shape[0])
+    perm = np.r_[0, perm[perm != 0]]          # new index i holds old camera perm[i]
+    inv = np.empty_like(perm)
+    inv[perm] = np.arange(perm.shape[0])
+    return hipba.Problem(prob.poses[perm], prob.points, inv[prob.obs_pose].astype(np.int32), prob.obs_point, prob.obs_uv,
+                         prob.K, prob.camera_model, prob.pose_const[perm], prob.point_const)
+
+
+@pytest.mark.parametrize("numbering", ["as_generated", "shuffled"])
+def test_envelope_factorisation_matches_oracle_log(solver, oracle, numbering):
+    """240 cameras on a long narrow grid: co-visibility reaches 47 cameras, the reduced matrix (1434 unknowns, 12 tile
+    rows) is a band and the dense factorisation skips the tiles outside its envelope.  As generated the cameras are
+    numbered along the grid: the host's ordering step tries reverse Cuthill-McKee and keeps the natural order.  With
+    the cameras renumbered at random the natural order has no band and the reverse Cuthill-McKee order is taken.  Both
+    against the oracle, which factors the full matrix in the caller's order."""
+    prob = banded_scene()
+    if numbering == "shuffled":
+        prob = _shuffled_cameras(prob, 1)
+    order = hipba.pose_order(prob)
+    variable_in_order = order[order != 0]
+    natural = bool(np.all(np.diff(variable_in_order) > 0))
+    assert natural == (numbering == "as_generated")
+    g = prob.copy()
+    s = solver.solve(g, hipba.default_options(max_num_iterations=8))
+    o = to_oracle(oracle, prob)
+    so, oits = oracle.solve(o, oracle.default_options(max_num_iterations=8, jacobian_mode=oracle.JAC_ANALYTIC, num_threads=16))
+    assert s["linear_solver_used"] == hipba.LINEAR_DENSE_CHOLESKY
+    assert s["termination_type"] == so["termination_type"]
+    assert len(s["iterations"]) >= 3
+    assert_logs_match(s["iterations"], oits)
+    assert abs(s["final_cost"] - so["final_cost"]) <= RTOL_COST * so["final_cost"]
+    assert np.abs(g.poses - o.poses).max() <= ATOL_STATE and np.abs(g.points - o.points).max() <= ATOL_STATE
+    # the envelope really is narrower than the matrix: fewer flops than the dense factorisation
+    dp = solver.upload(prob)
+    dense, inside = dp.reduced_solve_flops()
+    dp.free()
+    assert inside < 0.8 * dense
+
+
+def test_1024_batched_windows_at_the_stated_size(solver, oracle):
+    """BASELINE.json's batched configuration at its size: 1024 independent windows of 10 keyframes x 2000 landmarks
+    (~14k observations each, seeds 2000 + w, production semantics) in ONE hipba_solve_batched call.  Every window
+    converges below its starting cost; eight of them, spread over the batch, are compared with the oracle in full."""
+    n_w = 1024
+    wins = [scenes.small_window(2000 + w)[0] for w in range(n_w)]
+    assert sum(w.obs_pose.shape[0] for w in wins) > 13_000 * n_w
+    batch = [w.copy() for w in wins]
+    res = solver.solve_batched(batch, hipba.reference_production_options(), log=True)
+    assert len(res) == n_w
+    for w in range(n_w):
+        assert res[w]["termination_type"] == hipba.CONVERGENCE, w
+        assert res[w]["final_cost"] < res[w]["initial_cost"], w
+        assert res[w]["num_active_poses"] == 9
+    for w in (0, 1, 127, 300, 511, 512, 800, 1023):
+        o = to_oracle(oracle, wins[w])
+        so, oits = oracle.solve(o, oracle.default_options(max_num_iterations=300, jacobian_mode=oracle.JAC_ANALYTIC))
+        assert res[w]["termination_type"] == so["termination_type"]
+        assert abs(res[w]["final_cost"] - so["final_cost"]) <= RTOL_COST * so["final_cost"]
+        assert_logs_match(res[w]["iterations"], oits)
+        assert np.abs(batch[w].poses - o.poses).max() <= ATOL_STATE
+        assert np.abs(batch[w].points - o.points).max() <= ATOL_STATE
+
+
+def test_se3_plus_on_the_device_matches_oracle(solver, oracle):
+    """Sophus::Manifold<SE3>::Plus (optimizer.cpp:17,27) as the engine's pose update computes it, value by value
+    against the oracle's restatement: generic steps, steps below Sophus' small-angle switch (|omega| < 1e-10),
+    zero steps, rotations near pi, and poses whose quaternion is a little off unit length (the product renormalises
+    to first order only)."""
+    rng = np.random.default_rng(11)
+    n = 4096
+    q = rng.normal(size=(n, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    q[n // 2:] *= 1.0 + rng.normal(0.0, 1e-6, (n - n // 2, 1))
+    poses = np.concatenate([q, rng.normal(0.0, 30.0, (n, 3))], axis=1)
+    deltas = rng.normal(0.0, 0.3, (n, 6))
+    deltas[:256, 3:] *= 1e-12                      # below the small-angle switch
+    deltas[256:512, 3:] = 0.0                      # pure translation
+    deltas[512:768] = 0.0                          # identity
+    axis = rng.normal(size=(256, 3))
+    axis /= np.linalg.norm(axis, axis=1, keepdims=True)
+    deltas[768:1024, 3:] = axis * (np.pi - rng.uniform(0.0, 1e-6, (256, 1)))
+    deltas[1024:1280, 3:] *= 1e-9 / 0.3            # just above the switch
+    got = solver.se3_plus(poses, deltas)
+    want = np.array([oracle.se3_plus(poses[i], deltas[i]) for i in range(n)])
+    assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
+    # the identity step returns the pose itself whenever its quaternion has unit length to the last bit
+    unit = (poses[512:768, :4] ** 2).sum(axis=1) == 1.0
+    np.testing.assert_array_equal(got[512:768][unit], poses[512:768][unit])
+    # the pose of the reference's test/sophus_test.cpp (yaw 30 degrees, t = (1, 1, 0)) turned back by its own yaw
+    T = np.array([0.0, 0.0, np.sin(np.pi / 12), np.cos(np.pi / 12), 1.0, 1.0, 0.0])
+    step = np.array([0.25, -0.5, 0.0, 0.0, 0.0, -np.pi / 6])
+    got1 = solver.se3_plus(T.reshape(1, 7), step.reshape(1, 6))[0]
+    assert np.abs(got1 - oracle.se3_plus(T, step)).max() <= 1e-15
+    assert np.abs(got1[:4] - np.array([0.0, 0.0, 0.0, 1.0])).max() <= 1e-15
+
+
+def test_batch_mixing_windows_the_batched_kernels_cannot_take(solver, oracle):
+    """hipba_solve_batched keeps each window's reduced system in LDS (at most 32 variable poses).  The reference sets
+    no such limit (optimizer.cpp:25-51): a batch may hold larger windows too, which the call routes through the
+    single-window path; every window's result is what the oracle gives."""
+    frames = [6, 40, 10, 36, 3]
+    wins = [scenes.small_window(4300 + i, n_frames=nf, n_points=400)[0] for i, nf in enumerate(frames)]
+    batch = [w.copy() for w in wins]
+    res = solver.solve_batched(batch, hipba.reference_production_options(), log=True)
+    for w, g, s, nf in zip(wins, batch, res, frames):
+        assert s["num_active_poses"] == nf - 1
+        o = to_oracle(oracle, w)
+        so, oits = oracle.solve(o, oracle.default_options(max_num_iterations=300, jacobian_mode=oracle.JAC_ANALYTIC, num_threads=8))
+        assert s["termination_type"] == so["termination_type"]
+        assert abs(s["final_cost"] - so["final_cost"]) <= RTOL_COST * so["final_cost"]
+        assert_logs_match(s["iterations"], oits)
+        assert np.abs(g.poses - o.poses).max() <= ATOL_STATE and np.abs(g.points - o.points).max() <= ATOL_STATE
+    # a resident batch (hipba_upload) keeps the limit and says so
+    with pytest.raises(hipba.HipbaError) as ex:
+        solver.upload(wins)
+    assert ex.value.code == hipba.ERR_UNSUPPORTED

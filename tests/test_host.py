@@ -14,12 +14,12 @@ from stereo_visual_odometry_amd import harness, hipba, scenes, vo
 def test_library_loads_and_exports_header_symbols():
     lib = hipba.load_library()
     header = open(os.path.join(ROOT, "include", "hipba.h")).read()
-    declared = sorted(set(re.findall(r"\b(hipba_[a-z_]+)\s*\(", header)) - {"hipba_allreduce_fn"})
+    declared = sorted(set(re.findall(r"\b(hipba_[a-z0-9_]+)\s*\(", header)) - {"hipba_allreduce_fn"})
     assert declared, "no declarations found"
     for name in declared:
         assert hasattr(lib, name), "libhipba.so does not export %s" % name
     assert sorted(hipba.EXPORTED_SYMBOLS) == declared
-    assert lib.hipba_version() == 102 == hipba.ABI_VERSION
+    assert lib.hipba_version() == 103 == hipba.ABI_VERSION
 
 
 def test_options_default_match_ceres_defaults():
