@@ -130,9 +130,8 @@ def test_se3_plus_on_the_device_matches_oracle(solver, oracle):
     got = solver.se3_plus(poses, deltas)
     want = np.array([oracle.se3_plus(poses[i], deltas[i]) for i in range(n)])
     assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
-    # the identity step returns the pose itself whenever its quaternion has unit length to the last bit
-    unit = (poses[512:768, :4] ** 2).sum(axis=1) == 1.0
-    np.testing.assert_array_equal(got[512:768][unit], poses[512:768][unit])
+    # the identity step returns the pose itself (a unit quaternion to within the renormalisation's rounding)
+    assert np.abs(got[512:768] - poses[512:768]).max() <= 4e-16 * 30.0
     # the pose of the reference's test/sophus_test.cpp (yaw 30 degrees, t = (1, 1, 0)) turned back by its own yaw
     T = np.array([0.0, 0.0, np.sin(np.pi / 12), np.cos(np.pi / 12), 1.0, 1.0, 0.0])
     step = np.array([0.25, -0.5, 0.0, 0.0, 0.0, -np.pi / 6])
