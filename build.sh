@@ -30,3 +30,5 @@ g++ -O2 -std=c++17 -Wall -pthread -Iinclude -I$SRC/host -o $OUT/ba_sequences $SR
 echo "built $OUT/ba_sequences"
 g++ -O2 -std=c++17 -Wall -pthread -Iinclude -I$SRC/host -o $OUT/host_selftest $SRC/host/host_selftest.cpp -L$OUT -lhipba -Wl,-rpath,'$ORIGIN'
 echo "built $OUT/host_selftest"
+g++ -O2 -std=c++17 -Wall -pthread -Iinclude -I$SRC/host -o $OUT/kitti_runner $SRC/host/kitti_runner_cli.cpp -L$OUT -lhipba -Wl,-rpath,'$ORIGIN'
+echo "built $OUT/kitti_runner"

@@ -100,3 +100,51 @@ def test_cpp_reader_agrees_with_python(sequence):
     assert np.abs(last - pk.ground_truth_poses_[-1]).max() < 1e-6
     bad = subprocess.run([exe, d + "_missing"], capture_output=True, text=True)
     assert bad.returncode == 1 and "Could not open file" in bad.stderr
+
+
+def _write_curved_sequence(tmp_path, n=120):
+    """A KITTI-layout directory (times.txt at 10 Hz, sequence 00's calib.txt, no images) and a ground-truth file of a
+    car-like trajectory in KITTI's camera frame (z forward, x right, y down): ~1 m per frame along a gentle S-curve."""
+    d = tmp_path / "07"
+    d.mkdir()
+    (d / "times.txt").write_text("".join("%.6e\n" % (0.1 * i) for i in range(n)))
+    (d / "calib.txt").write_text(CALIB)
+    lines, pos, yaw = [], np.zeros(3), 0.0
+    for i in range(n):
+        R = _rot([0, 1, 0], yaw)
+        T = np.hstack([R, pos.reshape(3, 1)])
+        lines.append(" ".join("%.9e" % v for v in T.reshape(-1)))
+        yaw += 0.012 * np.sin(2 * np.pi * i / 60.0)
+        pos = pos + _rot([0, 1, 0], yaw) @ np.array([0.0, 0.0, 0.9 + 0.2 * np.sin(0.3 * i)])
+    gt = tmp_path / "07.txt"
+    gt.write_text("\n".join(lines) + "\n")
+    return str(d), str(gt)
+
+
+@pytest.mark.gpu
+def test_kitti_runner_over_a_sequence_directory(tmp_path):
+    """The ROS-free runner (template: reference test/valgrind_main.cpp:20-42) on a KITTI-layout directory built here:
+    loaders -> left camera's K -> per-frame stage with the reference's BA trigger -> GPU solves -> trajectory error
+    against the ground-truth file.  The image half of the frontend is the synthetic one (no OpenCV here), which
+    dead-reckons along the loaded trajectory: with bundle adjustment the absolute trajectory error must come out
+    smaller than without, and the windows must have been solved on the GPU."""
+    exe = os.path.join(LIB, "kitti_runner")
+    d, gt = _write_curved_sequence(tmp_path)
+    r = subprocess.run([exe, d, "--poses", gt, "--both"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    out = r.stdout.strip().split("\n")
+    head = out[0].split()
+    assert int(head[head.index("frames") + 1]) == 120 and int(head[head.index("cameras") + 1]) == 2
+    assert float(head[head.index("fx") + 1]) == pytest.approx(718.856) and float(head[head.index("cy") + 1]) == pytest.approx(185.2157)
+    assert float(head[head.index("baseline_m") + 1]) == pytest.approx(386.1448 / 718.856, rel=1e-6)
+    off, on = out[1].split(), out[2].split()
+    assert off[:2] == ["bundle_adjustment", "off"] and on[:2] == ["bundle_adjustment", "on"]
+    get = lambda f, k: float(f[f.index(k) + 1])
+    assert get(off, "windows") == 0 and get(on, "windows") == 5          # frames 20, 40, ... 100 (frontend.cpp:71)
+    assert get(on, "ate_rmse_m") < 0.6 * get(off, "ate_rmse_m")
+    assert get(on, "ate_rmse_m") < 1.0
+    # the reference's trajectory bookkeeping (frontend.cpp:74-81): one entry per step, one more per splice
+    assert get(off, "trajectory_entries") == 119
+    # a sequence directory that is not there
+    bad = subprocess.run([exe, d + "_missing"], capture_output=True, text=True)
+    assert bad.returncode == 1 and "Could not open file" in bad.stderr
