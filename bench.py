@@ -92,6 +92,40 @@ def load_traffic(workload_key):
     return tr.get("kernels", {})
 
 
+SHADER_CLOCK_GHZ = 2.4   # MI355X peak engine clock
+SIMDS = 1024             # 256 compute units x 4
+# bench.py's kernel names -> the kernels (as rocprofv3 names them) one launch is made of
+ISSUE_MEMBERS = {"residual": ["k_cost"], "residual_jacobian": ["k_residual_jacobian"], "camera_blocks": ["k_camera_blocks"],
+                 "point_schur": ["k_point_schur<2>", "k_schur_gather"], "backsub": ["k_backsub<true>"]}
+
+
+def load_issue(workload_key):
+    """Vector instructions per launch from a rocprofv3 PMC pass of SQ counters (scripts/profile_all.sh +
+    scripts/summarize_sq.py), or {} if the file is absent or belongs to another workload or other kernel sources."""
+    path = os.path.join(ROOT, "profiles", "issue.json")
+    if not os.path.exists(path):
+        return {}
+    doc = json.load(open(path))
+    if doc.get("csrc_sha256") != csrc_fingerprint() or doc.get("workload") != workload_key:
+        return {}
+    return doc.get("kernels", {})
+
+
+def add_vector_issue_bound(rows, issue):
+    """A second bound for the kernels that recompute their Jacobians in fp64: the time the vector units need just to
+    ISSUE the launch's vector instructions (SQ_INSTS_VALU per wave x waves, four cycles per wave64 instruction -- the
+    full-rate cost; fp64 divisions and square roots take more -- spread over all SIMDs at the peak clock).  A kernel
+    can be no faster than that however little memory it touches; `frac` = that floor / the measured duration."""
+    for k in rows:
+        members = ISSUE_MEMBERS.get(k["kernel"])
+        if not members or not all(m in issue for m in members):
+            continue
+        insts = sum(issue[m]["valu_insts_per_wave"] * issue[m]["waves_per_call"] for m in members)
+        floor_ms = 1e3 * insts * 4.0 / (SIMDS * SHADER_CLOCK_GHZ * 1e9)
+        k["vector_issue"] = {"bound": "valu", "wave_instructions": insts, "floor_ms": floor_ms, "frac": floor_ms / k["ms"],
+                             "issuing_frac_of_wave_cycles": max(issue[m]["issuing_frac"] for m in members)}
+
+
 def kernel_table(dp, hipba, opts, n_c, n_p, n_o, nnz, flops_solve, single_window):
     """Average launch duration of every hot-path kernel on the resident problem (HIP events on the engine's
     stream) against its algorithmic bytes / flops."""
@@ -530,6 +564,7 @@ def main():
         for k in kernels:
             if k["kernel"] in traffic:
                 k["traffic"] = traffic[k["kernel"]]["hbm_bytes"]
+        add_vector_issue_bound(kernels, load_issue("bal_scale %d %d %d world %d" % (n_c, n_p, n_o, world)))
         roof = roofline_of(kernels)
         result = {
             "metric": "BA LM iterations/sec", "value": steps_done / elapsed, "unit": "LM iterations/s",

@@ -282,17 +282,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #define PIPE_LREAD(buf, kk, fa_, fb_)                                                                          \
   {                                                                                                            \
     const int kr_ = (kk) * 4 + (lane >> 4);                                                                    \
-    fa_ = sB[buf][kr_ * LDS_ + (lane & 15) + wave * 16];                                                       \
+    fa_[0] = sB[buf][kr_ * LDS_ + (lane & 15) + wave * 16];                                                    \
+    if (MODE == 2) {                                                                                           \
+      fa_[1] = sB[buf][kr_ * LDS_ + ((lane - 4) & 15) + wave * 16];                                            \
+      fa_[2] = sB[buf][kr_ * LDS_ + ((lane - 8) & 15) + wave * 16];                                            \
+      fa_[3] = sB[buf][kr_ * LDS_ + ((lane - 12) & 15) + wave * 16];                                           \
+    }                                                                                                          \
     _Pragma("unroll") for (int m = 0; m < 4; ++m) fb_[m] = sA[buf][kr_ * LDS_ + (lane & 15) + m * 16];         \
   }
 #define PIPE_MATH(fa_, fb_)                                                                                    \
   {                                                                                                            \
     if (MODE == 0) {                                                                                           \
-      _Pragma("unroll") for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa_, fb_[b], acc[b], 0, 0, 0); \
+      _Pragma("unroll") for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa_[0], fb_[b], acc[b], 0, 0, 0); \
     } else {                                                                                                   \
-      const double f1_ = rot_groups<0x124>(fa_), f2_ = rot_groups<0x128>(fa_), f3_ = rot_groups<0x12c>(fa_);   \
+      const double f1_ = MODE == 2 ? fa_[1] : rot_groups<0x124>(fa_[0]);                                       \
+      const double f2_ = MODE == 2 ? fa_[2] : rot_groups<0x128>(fa_[0]);                                       \
+      const double f3_ = MODE == 2 ? fa_[3] : rot_groups<0x12c>(fa_[0]);                                       \
       _Pragma("unroll") for (int b = 0; b < 4; ++b) {                                                          \
-        acc[b][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa_, fb_[b], acc[b][0], 0, 0, 0);                       \
+        acc[b][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa_[0], fb_[b], acc[b][0], 0, 0, 0);                    \
         acc[b][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(f1_, fb_[b], acc[b][1], 0, 0, 0);                       \
         acc[b][2] = __builtin_amdgcn_mfma_f64_4x4x4f64(f2_, fb_[b], acc[b][2], 0, 0, 0);                       \
         acc[b][3] = __builtin_amdgcn_mfma_f64_4x4x4f64(f3_, fb_[b], acc[b][3], 0, 0, 0);                       \
@@ -300,7 +307,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }                                                                                                          \
   }
   PIPE_GLOAD(0, 0, row0, col0); PIPE_GLOAD(1, 1, row0, col0); PIPE_GLOAD(2, 2, row0, col0); PIPE_GLOAD(3, 3, row0, col0);
-  double fa0, fb0[4], fa1, fb1[4];
+  double fa0[4], fb0[4], fa1[4], fb1[4];
   PIPE_LWRITE(0, 0);
   PIPE_GLOAD(0, 4, row0, col0);
   __syncthreads();
@@ -442,6 +449,7 @@ int main(int argc, char** argv) {
   g_lds = 76000;
   t = run_pipe<0>(d, init, o1, ld, rows, grid, 20); check("pipelined 16x16x4", t, o1);
   t = run_pipe<1>(d, init, o1, ld, rows, grid, 20); check("pipelined 4x4x4 + dpp", t, o1);
+  t = run_pipe<2>(d, init, o1, ld, rows, grid, 20); check("pipelined 4x4x4, lds rot", t, o1);
   for (int g : {510}) {
     char nm[64];
     snprintf(nm, sizeof nm, "direct 32x32 D4, grid %d", g);

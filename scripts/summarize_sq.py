@@ -2,7 +2,7 @@
 where a wave's cycles go (parked on a wait or barrier / stalled at issue / issuing) and how many vector instructions
 it executes.  The SQ cycle counters are in quad-cycles (x4 = shader cycles).
 
-Usage: python scripts/summarize_sq.py <pmc directory> <out.json>"""
+Usage: python scripts/summarize_sq.py <pmc directory> <out.json> [workload key]"""
 import csv, glob, json, os, sys
 from collections import defaultdict
 
@@ -30,7 +30,11 @@ def main():
         print("%-28s %6d %9.0f %9.0f %6.1f%% %6.1f%% %6.1f%% %6.1f%% %9.0f" % (
             name[:28], n, e["waves_per_call"], e["cycles_per_wave"], 100 * e["parked_frac"], 100 * e["issue_stall_frac"],
             100 * e["issuing_frac"], 100 * e["valu_frac"], e["valu_insts_per_wave"]))
-    json.dump(out, open(sys.argv[2], "w"), indent=1)
+    # stamped with the kernel sources and the workload the counters belong to: bench.py ignores the file otherwise
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import csrc_fingerprint
+    doc = {"csrc_sha256": csrc_fingerprint(), "workload": sys.argv[3] if len(sys.argv) > 3 else "", "kernels": out}
+    json.dump(doc, open(sys.argv[2], "w"), indent=1)
 
 
 if __name__ == "__main__":
