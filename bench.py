@@ -33,6 +33,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E, spec
 FP64_PEAK_TFLOPS = 78.6    # MI355X fp64 matrix / vector, spec
+MFMA_F64_16X16X4_TFLOPS = 48.5  # measured on MI355X: the most v_mfma_f64_16x16x4_f64 delivers chip-wide (register operands)
 TERMINATION = ["CONVERGENCE", "NO_CONVERGENCE", "FAILURE"]
 
 
@@ -147,7 +148,12 @@ def kernel_table(dp, hipba, opts, n_c, n_p, n_o, nnz, flops_solve, single_window
             rows.append({"kernel": name, "bound": "mfma", "ms": ms, "achieved": ach, "peak": FP64_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS, "traffic": None,
                          "algorithmic_flops": flops, "dense_flops": dense,
-                         "dense_equivalent_tflops": dense / (ms * 1e-3) / 1e12})
+                         "dense_equivalent_tflops": dense / (ms * 1e-3) / 1e12,
+                         # what the instruction the factorisation is built on sustains over the whole chip from
+                         # registers alone, at any occupancy (scripts/bench_fp64_rates.hip): the nominal peak is only
+                         # reached by v_mfma_f64_4x4x4_4b_f64 (75 TFLOP/s), which lost inside the band update
+                         "instruction_ceiling": {"instruction": "v_mfma_f64_16x16x4_f64", "tflops": MFMA_F64_16X16X4_TFLOPS,
+                                                 "frac": ach / MFMA_F64_16X16X4_TFLOPS}})
         else:
             ach = algorithmic_bytes(name, n_c, n_p, n_o, nnz) / (ms * 1e-3) / 1e9
             rows.append({"kernel": name, "bound": "hbm", "ms": ms, "achieved": ach, "peak": HBM_PEAK_GBS,
@@ -159,7 +165,7 @@ def roofline_of(rows):
     in_loop = [k for k in rows if k["kernel"] != "residual_jacobian"]
     dom = max(in_loop, key=lambda k: k["ms"])
     out = {k: dom[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
-    for k in ("algorithmic_flops", "dense_equivalent_tflops"):
+    for k in ("algorithmic_flops", "dense_equivalent_tflops", "instruction_ceiling"):
         if k in dom:
             out[k] = dom[k]
     out["kernel"] = dom["kernel"]

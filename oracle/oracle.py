@@ -68,6 +68,7 @@ class CSummary(C.Structure):
 
 
 _lib = None
+_variants = {}
 
 
 def build():
@@ -75,8 +76,21 @@ def build():
     subprocess.check_call(["make", "-C", _HERE, "-s"])
 
 
-def lib():
+def lib(variant=None):
+    """The oracle library.  variant="fma": the same source compiled with fused multiply-adds allowed
+    (libba_oracle_fma.so) -- a second rounding of the same arithmetic, which tests use to tell how far apart two
+    correct fp64 evaluations of one ill-conditioned step may land; it only serves solve()."""
     global _lib
+    if variant is not None:
+        if variant not in _variants:
+            path = os.path.join(_HERE, "libba_oracle_%s.so" % variant)
+            if not os.path.exists(path):
+                build()
+            v = C.CDLL(path)
+            v.oracle_solve.argtypes = [C.POINTER(CProblem), C.POINTER(COptions), C.POINTER(CSummary), C.POINTER(CIteration)]
+            v.oracle_solve.restype = C.c_int
+            _variants[variant] = v
+        return _variants[variant]
     if _lib is None:
         if not os.path.exists(_LIB_PATH):
             build()
@@ -212,13 +226,13 @@ def evaluate(prob, jacobian_mode=JAC_ANALYTIC, loss=LOSS_NONE, loss_scale=1.0, a
     return out
 
 
-def solve(prob, options=None):
+def solve(prob, options=None, variant=None):
     """Runs the restated Ceres solve in place on prob; returns (summary dict, iteration list)."""
     o = options if options is not None else default_options()
     s = CSummary()
     log = (CIteration * (o.max_num_iterations + 2))()
     cp = prob.c()
-    rc = lib().oracle_solve(C.byref(cp), C.byref(o), C.byref(s), log)
+    rc = lib(variant).oracle_solve(C.byref(cp), C.byref(o), C.byref(s), log)
     summ = {f[0]: getattr(s, f[0]) for f in CSummary._fields_}
     summ["rc"] = rc
     its = [{f[0]: getattr(log[i], f[0]) for f in CIteration._fields_} for i in range(s.num_iterations)]
