@@ -1,5 +1,7 @@
-"""Rehearsal of the multi-rank path on a one-GPU box: N ranks on device 0, gloo collectives on CUDA tensors through
-the same TorchComm that RCCL uses on a multi-GPU node.  Launch with torch.distributed.run."""
+"""One rank of a sharded solve on a one-GPU box: N PROCESSES on device 0, the engine's all-reduces carried by gloo on
+CUDA tensors through the same TorchComm callback a torch.distributed job uses.  Launched with torch.distributed.run by
+tests/test_sharded_processes.py (and by hand: python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1
+tests/sharded_rank_main.py [n_points] [band]); rank 0 prints the comparison with the same window solved whole."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -163,3 +163,21 @@ def test_cpp_host_headers_selftest(tmp_path):
     out = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=60)
     assert out.returncode == 0, out.stdout + out.stderr
     assert " 0 failed" in out.stdout
+
+
+def test_bench_launches_its_own_ranks_when_started_plainly():
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks itself (torch.distributed.run as a child
+    process) and hands their exit code on.  Without a GPU every rank stops at once with the engine's "no CPU path"
+    message -- which is how this test, on a CPU, sees that two ranks were started with the right world size."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("on a GPU box this would run the whole benchmark; see tests/manual_sharded_processes.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert out.returncode != 0
+    assert out.stderr.count("bench.py needs an MI355X") >= 2, out.stderr[-2000:]
+    assert "--nproc-per-node" not in out.stdout  # the launcher's own command line is not echoed as a result line
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
