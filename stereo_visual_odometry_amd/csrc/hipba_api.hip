@@ -737,6 +737,44 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   }
 
   SETUP_MARK("gathered lists");
+  // ---- camera-major lists and the parameters in device order -----------------------------------------
+  // Independent of the run lists below: on small windows the caller's thread builds them while the handle's workers
+  // group the pairs (what used to be two steps one after the other).
+  std::vector<long long> cm_start(n_slots + 1, 0);
+  std::vector<int> cm_dp;
+  std::vector<double> cm_uv;
+  std::vector<double> poses(std::max<long long>(7 * NP, 7)), points(std::max<long long>(3 * NPT, 3));
+  bool side_lists_done = false;
+  auto build_side_lists = [&]() {
+    for (long long o = 0; o < n_act_obs; ++o) {
+      const int g = pose_gslot[obs_pose[o]];
+      if (g >= 0) cm_start[g + 1]++;
+    }
+    for (int g = 0; g < n_slots; ++g) cm_start[g + 1] += cm_start[g];
+    const long long n_cm = cm_start[n_slots];
+    cm_dp.resize(std::max<long long>(n_cm, 1));
+    cm_uv.resize(std::max<long long>(2 * n_cm, 2));
+    {
+      std::vector<long long> cur(cm_start.begin(), cm_start.end() - 1);
+      for (long long o = 0; o < n_act_obs; ++o) {
+        const int g = pose_gslot[obs_pose[o]];
+        if (g < 0) continue;
+        const long long dst = cur[g]++;
+        cm_dp[dst] = obs_dp[o];
+        cm_uv[2 * dst] = obs_uv[2 * o]; cm_uv[2 * dst + 1] = obs_uv[2 * o + 1];
+      }
+    }
+    for (int w = 0; w < nw; ++w) {
+      const hipba_problem& p = probs[w];
+      if (p.n_poses) memcpy(poses.data() + 7ll * R->meta[w].pose_base, p.poses, sizeof(double) * 7 * p.n_poses);
+      for (int i = 0; i < p.n_points; ++i) {
+        const int dp = dp_of[pt_base[w] + i];
+        points[3ll * dp] = p.points[3 * i]; points[3ll * dp + 1] = p.points[3 * i + 1]; points[3ll * dp + 2] = p.points[3 * i + 2];
+      }
+    }
+    side_lists_done = true;
+  };
+
   // ---- atomic / LDS accumulation: each block's pair list grouped by destination block and cut into runs
   // of at most kRunMax pairs with one destination; a lane group sums a run in registers and adds it to
   // the reduced matrix once ------------------------------------------------------------------------
@@ -837,8 +875,9 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
     if (n_thr <= 1) {
       group_range(0, 0, n_blk_pm);
     } else if (n_thr <= 8) {
-      // the handle's sleeping workers
-      if (!h->workers.run(n_thr, [&](int i) { group_range(i, lo(i), lo(i + 1)); }))
+      // the handle's sleeping workers take the blocks; the caller's thread (part 0 of the job) builds the camera-major
+      // lists and the device-order parameters meanwhile
+      if (!h->workers.run(n_thr + 1, [&](int i) { if (i == 0) build_side_lists(); else group_range(i - 1, lo(i - 1), lo(i)); }))
         return fail(HIPBA_ERR_OUT_OF_MEMORY, "host analysis of the pair lists ran out of memory");
     } else {
       // short-lived threads for a large problem; an exception of a part stays inside its thread, and a thread that
@@ -875,26 +914,8 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   }
 
   SETUP_MARK("runs");
-  // ---- camera-major lists ------------------------------------------------------------------------
-  std::vector<long long> cm_start(n_slots + 1, 0);
-  for (long long o = 0; o < n_act_obs; ++o) {
-    const int g = pose_gslot[obs_pose[o]];
-    if (g >= 0) cm_start[g + 1]++;
-  }
-  for (int g = 0; g < n_slots; ++g) cm_start[g + 1] += cm_start[g];
-  const long long n_cm = cm_start[n_slots];
-  std::vector<int> cm_dp(std::max<long long>(n_cm, 1));
-  std::vector<double> cm_uv(std::max<long long>(2 * n_cm, 2));
-  {
-    std::vector<long long> cur(cm_start.begin(), cm_start.end() - 1);
-    for (long long o = 0; o < n_act_obs; ++o) {
-      const int g = pose_gslot[obs_pose[o]];
-      if (g < 0) continue;
-      const long long dst = cur[g]++;
-      cm_dp[dst] = obs_dp[o];
-      cm_uv[2 * dst] = obs_uv[2 * o]; cm_uv[2 * dst + 1] = obs_uv[2 * o + 1];
-    }
-  }
+  // ---- camera-major lists, parameters in device order: built by build_side_lists above, beside the run lists -----
+  if (!side_lists_done) build_side_lists();
   for (int w = 0; w < nw; ++w) {
     long long na = 0;
     for (int b = wd[w].pm_blk_begin; b < wd[w].pm_blk_end; ++b) na += blocks[b].n_obs;
@@ -904,17 +925,6 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   }
 
   SETUP_MARK("camera-major");
-  // ---- parameters in device order ----------------------------------------------------------------
-  std::vector<double> poses(std::max<long long>(7 * NP, 7)), points(std::max<long long>(3 * NPT, 3));
-  for (int w = 0; w < nw; ++w) {
-    const hipba_problem& p = probs[w];
-    if (p.n_poses) memcpy(poses.data() + 7ll * R->meta[w].pose_base, p.poses, sizeof(double) * 7 * p.n_poses);
-    for (int i = 0; i < p.n_points; ++i) {
-      const int dp = dp_of[pt_base[w] + i];
-      points[3ll * dp] = p.points[3 * i]; points[3ll * dp + 1] = p.points[3 * i + 1]; points[3ll * dp + 2] = p.points[3 * i + 2];
-    }
-  }
-
   SETUP_MARK("parameters");
   // ---- plan the arena ----------------------------------------------------------------------------
   P.n_poses = (int)NP; P.n_points = (int)NPT; P.n_act_poses = n_slots; P.n_pm_points = n_pm_points;
