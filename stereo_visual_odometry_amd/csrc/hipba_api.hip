@@ -1241,6 +1241,8 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
 
   // small windows: the control kernel of a pass zeroes S for the next one (see k_window_control)
   const bool control_zeroes_S = small && !sharded && !direct;
+  // development switch: HIPBA_SPLIT_LINEARIZE=1 keeps the camera blocks and the elimination in two launches (A/B timing)
+  static const bool split_linearize = getenv("HIPBA_SPLIT_LINEARIZE") != nullptr;
   int iterations_run = 0;
   for (int iter = 1; iter <= std::max(lm.max_num_iterations, 0); ++iter) {
     PHASE(0);
@@ -1251,13 +1253,18 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
       HIPBA_HIP(hipMemsetAsync(P.S, 0, sizeof(double) * (size_t)R->S_doubles, s));
     }
     const bool fuse_init = iter > 1 && !sharded;
-    if (iter > 1) {
+    // small windows from the second pass on: S and b were left zeroed by the control kernel, and one launch forms
+    // the camera blocks, initialises the reduced system and eliminates the landmarks
+    const bool one_launch = control_zeroes_S && iter > 1 && !timing && !split_linearize && P.n_act_poses > 0 && !P.prec;
+    if (one_launch) {
+      HIPBA_HIP(launch_small_linearize(P, lm, small_ncam, schur_parts, s));
+    } else if (iter > 1) {
       HIPBA_HIP(launch_camera_blocks(P, lm, 1, fuse_init ? 1 : 0, s));
       if (sharded && P.n_act_poses) { AR(P.U, 36 * (size_t)P.n_act_poses, HIPBA_REDUCE_SUM); AR(P.gc, 6 * (size_t)P.n_act_poses, HIPBA_REDUCE_SUM); }
     }
     PHASE(1);
     if (!fuse_init) HIPBA_HIP(launch_init_reduced(P, lm, owner, s));
-    HIPBA_HIP(launch_point_schur(P, lm, small_ncam, schur_parts, s));
+    if (!one_launch) HIPBA_HIP(launch_point_schur(P, lm, small_ncam, schur_parts, s));
     if (sharded) {
       const bool piped = direct && feed.n_chunks > 0 && solver == HIPBA_LINEAR_DENSE_CHOLESKY;
       if (direct && !piped) {

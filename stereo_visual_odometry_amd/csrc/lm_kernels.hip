@@ -191,6 +191,9 @@ __global__ __launch_bounds__(kBlock) void k_cost(DevP P, LmParams lm, int blk_of
 //   S(c,c) = U_c + D_c^2,  b_c = g_c,  and the pose part of |x - Plus(x, -g)|.
 // S must have been zeroed on the stream before this kernel.
 // ------------------------------------------------------------------------------------------
+// ATOMIC: S and b of the window were zeroed earlier and other workgroups of the same launch are subtracting their
+// Schur products from them already: the diagonal block and the gradient are added, not stored (packed S only).
+template <bool ATOMIC = false>
 __device__ __forceinline__ void init_reduced_pose(const DevP& P, const LmParams& lm, int g, int owner) {
   const int c = P.slot_pose[g];
   const int w = P.pose_window[c];
@@ -213,6 +216,8 @@ __device__ __forceinline__ void init_reduced_pose(const DevP& P, const LmParams&
       if (P.dense_S) {
         // lower triangle only; in a sharded solve one rank contributes U + D^2 (the matrix was zeroed before)
         if (j >= i && owner) P.dense_S[(long long)(6 * slot + i) * P.dense_ld + 6 * slot + j] = v;
+      } else if (ATOMIC) {
+        atomic_add_f64(Sb + 6 * i + j, v);
       } else if (owner) {
         Sb[6 * i + j] = v;  // sharded solves: one rank contributes U + D^2 and g_c
       }
@@ -222,7 +227,8 @@ __device__ __forceinline__ void init_reduced_pose(const DevP& P, const LmParams&
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
     const double gs = P.gc[6ll * g + i];
-    P.b[6ll * g + i] = owner ? gs : 0.0;
+    if (ATOMIC) atomic_add_f64(P.b + 6ll * g + i, gs);
+    else P.b[6ll * g + i] = owner ? gs : 0.0;
     neg[i] = -gs / P.scale_c[6ll * g + i];
   }
   // gradient norms are defined through the retraction: |x - Plus(x, -g)|
@@ -267,9 +273,9 @@ __global__ void k_init_reduced(DevP P, LmParams lm, int owner) {
 // ------------------------------------------------------------------------------------------
 // fuse_init: thread 0 goes on to do k_init_reduced's work for this pose (S must have been zeroed before this
 // launch then): one launch less per iteration.
-__global__ __launch_bounds__(kBlock) void k_camera_blocks(DevP P, LmParams lm, int use_scale, int fuse_init) {
-  __shared__ double red[27 * 4];
-  const int g = blockIdx.x;
+// fuse_init 2: the same with S and b added to instead of stored (see init_reduced_pose<true>).
+__device__ __forceinline__ void camera_blocks_body(const DevP& P, const LmParams& lm, int g, int use_scale, int fuse_init,
+                                                   double* red) {
   const int c = P.slot_pose[g];
   const int w = P.pose_window[c];
   const WinState* st = P.ws + w;
@@ -311,8 +317,14 @@ __global__ __launch_bounds__(kBlock) void k_camera_blocks(DevP P, LmParams lm, i
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) P.gc[6ll * g + i] = acc[21 + i];
-    if (fuse_init) init_reduced_pose(P, lm, g, 1);
+    if (fuse_init == 2) init_reduced_pose<true>(P, lm, g, 1);
+    else if (fuse_init) init_reduced_pose(P, lm, g, 1);
   }
+}
+
+__global__ __launch_bounds__(kBlock) void k_camera_blocks(DevP P, LmParams lm, int use_scale, int fuse_init) {
+  __shared__ double red[27 * 4];
+  camera_blocks_body(P, lm, blockIdx.x, use_scale, fuse_init, red);
 }
 
 // Jacobi scaling of the pose columns, computed once at iteration 0 from the unscaled blocks
@@ -485,7 +497,7 @@ __device__ __forceinline__ void pair_products(const unsigned short* pairs, const
 //   whole packed S when it fits (MODE 1; MODE 3 sends S to HBM with atomics).  With S in LDS a lane forms whole
 //   products (one run each) instead of sharing one with eleven others: a third of the LDS bytes read per multiply-add.
 template <int MODE>
-__global__ __launch_bounds__(kBlock) void k_point_schur(DevP P, LmParams lm, int parts) {
+__device__ __forceinline__ void point_schur_body(const DevP& P, const LmParams& lm, int parts, const int bid) {
   constexpr bool SMALL = MODE == 1 || MODE == 3;
   constexpr bool LDS_S = MODE == 1;
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -500,10 +512,10 @@ __global__ __launch_bounds__(kBlock) void k_point_schur(DevP P, LmParams lm, int
 
   const int t = threadIdx.x;
   HIPBA_TICK(0);
-  int blk = blockIdx.x, blk_end = blockIdx.x + 1, blk_step = 1, w;
+  int blk = bid, blk_end = bid + 1, blk_step = 1, w;
   if (SMALL) {
-    w = blockIdx.x / parts;
-    const int part = blockIdx.x - w * parts;
+    w = bid / parts;
+    const int part = bid - w * parts;
     blk = P.wd[w].pm_blk_begin + part;
     blk_end = P.wd[w].pm_blk_end;
     blk_step = parts;
@@ -709,6 +721,27 @@ __global__ __launch_bounds__(kBlock) void k_point_schur(DevP P, LmParams lm, int
     }
   }
   HIPBA_TICK(7);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_point_schur(DevP P, LmParams lm, int parts) {
+  point_schur_body<MODE>(P, lm, parts, blockIdx.x);
+}
+
+// Small windows, second pass on: the camera blocks and the elimination of the landmarks in ONE launch.  The first
+// P.n_act_poses workgroups do k_camera_blocks' work for one pose each and ADD U + D^2 and g to the window's S and b;
+// the others do k_point_schur<MODE>'s.  S and b must hold zeros when the launch starts (k_window_control of the
+// pass before leaves them so).  Both halves are a few dozen workgroups of a few microseconds' dependent work: side
+// by side on the chip they cost the longer of the two, and one launch boundary less.
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_small_linearize(DevP P, LmParams lm, int parts) {
+  static_assert(MODE == 1 || MODE == 3, "small-window modes only");
+  if ((int)blockIdx.x < P.n_act_poses) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    camera_blocks_body(P, lm, blockIdx.x, 1, 2, smem);
+  } else {
+    point_schur_body<MODE>(P, lm, parts, (int)blockIdx.x - P.n_act_poses);
+  }
 }
 
 // gathered mode: S(block d) -= sum over its observation pairs of Y_i W_j^T.  A wave owns a chunk of the
@@ -1533,6 +1566,9 @@ __global__ __launch_bounds__(kWideBlock) void k_window_control(DevP P, LmParams 
   double2* Sw = reinterpret_cast<double2*>(P.S + wd.S_off);
   const long long n2 = 18ll * ((long long)wd.ncam * (wd.ncam + 1) / 2);
   for (long long i = threadIdx.x; i < n2; i += blockDim.x) Sw[i] = make_double2(0.0, 0.0);
+  // (and its right-hand side: k_small_linearize adds to both)
+  double2* bw = reinterpret_cast<double2*>(P.b + 6ll * wd.cam_base);
+  for (int i = threadIdx.x; i < 3 * wd.ncam; i += blockDim.x) bw[i] = make_double2(0.0, 0.0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2175,7 +2211,8 @@ size_t schur_lds_bytes(int small_ncam, bool staged) {
 // ON THE CURRENT DEVICE: called by hipba_create for every handle, with the handle's device current.
 hipError_t configure_lm_kernels() {
   const void* big[] = {reinterpret_cast<const void*>(&k_point_schur<0>), reinterpret_cast<const void*>(&k_point_schur<1>),
-                       reinterpret_cast<const void*>(&k_point_schur<2>), reinterpret_cast<const void*>(&k_point_schur<3>)};
+                       reinterpret_cast<const void*>(&k_point_schur<2>), reinterpret_cast<const void*>(&k_point_schur<3>),
+                       reinterpret_cast<const void*>(&k_small_linearize<1>), reinterpret_cast<const void*>(&k_small_linearize<3>)};
   for (const void* f : big) {
     const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
@@ -2244,6 +2281,20 @@ hipError_t launch_point_schur(const DevP& P, const LmParams& lm, int small_ncam,
   } else {
     hipLaunchKernelGGL(k_point_schur<0>, dim3(P.n_blk_pm), dim3(kBlock), schur_lds_bytes(0, false), s, P, lm, 1);
   }
+  return hipGetLastError();
+}
+
+// camera blocks (with the reduced system's initialisation) and landmark elimination of small windows in one launch;
+// S and b hold zeros (see k_small_linearize)
+hipError_t launch_small_linearize(const DevP& P, const LmParams& lm, int small_ncam, int parts, hipStream_t s) {
+  if (small_ncam <= 0 || P.n_act_poses <= 0 || P.prec) return hipErrorInvalidValue;
+  if (parts < 1) parts = 1;
+  const size_t lds = schur_lds_bytes(small_ncam, false);  // (the camera half needs 27 * 4 doubles of it)
+  const unsigned grid = (unsigned)P.n_act_poses + (P.n_blk_pm > 0 ? (unsigned)P.n_windows * (unsigned)parts : 0u);
+  if (small_ncam <= kLdsSMaxCam)
+    hipLaunchKernelGGL(k_small_linearize<1>, dim3(grid), dim3(kBlock), lds, s, P, lm, parts);
+  else
+    hipLaunchKernelGGL(k_small_linearize<3>, dim3(grid), dim3(kBlock), lds, s, P, lm, parts);
   return hipGetLastError();
 }
 
