@@ -174,6 +174,8 @@ struct DevP {
   double* gpart;    // [2 * n_blk_pm] landmark gradient max / sum of squares per PM block
   double* wsum;     // [8 * n_windows] per-window sums handed to the all-reduce of sharded solves
   int sharded;      // 1 when this rank holds only a shard of the window's landmarks
+  int dest_owned;   // small windows: the elimination lets every lane own one block of S and find its products itself
+                    // (no pair or run lists were built: see point_schur_body, MODE 4)
   hipba_iteration* log;
   int log_cap;      // entries per window
 };

@@ -550,6 +550,7 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   // variable.  Only the sizes are fixed here (every list 16-byte aligned: blocks load them as uint4); the lists are
   // written further down, already in the order the accumulation mode wants.
   long long pairs_total = 0, pairs_all = 0;
+  bool has_dup = false;  // some variable pose observes some landmark more than once
   std::vector<LongDesc> longs;
   for (int w = 0; w < nw; ++w) {
     wd[w].pm_blk_begin = (int)blocks.size();
@@ -596,7 +597,7 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
         for (int i = n, run = 1; i < s1; ++i) {
           const bool same = i + 1 < s1 && obs_pose[d.obs_begin + i + 1] == obs_pose[d.obs_begin + i];
           if (same) { ++run; continue; }
-          if (pose_gslot[obs_pose[d.obs_begin + i]] >= 0) np += run * (run - 1) / 2;
+          if (pose_gslot[obs_pose[d.obs_begin + i]] >= 0) { np += run * (run - 1) / 2; has_dup |= run > 1; }
           run = 1;
         }
         n = s1;
@@ -610,8 +611,17 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
     }
     wd[w].pm_blk_end = (int)blocks.size();
   }
+  // Small windows (the reduced system solved in LDS) of at most 32 poses, no pose observing a landmark twice: every
+  // lane of the elimination owns one block of S and finds its products itself from the landmarks' slot masks
+  // (point_schur_body, MODE 4) -- no pair list, no run list, nothing to group here or to upload.
+  // HIPBA_PAIR_LISTS=1 keeps the lists (A/B timing).
+  static const bool keep_pair_lists = getenv("HIPBA_PAIR_LISTS") != nullptr;
+  // (a single window with millions of products goes to the gathered elimination below, as before)
+  const bool gathered_instead = nw == 1 && max_ncam > 20 && pairs_all + 8 >= 2000000;
+  const bool dest_owned = !keep_pair_lists && !has_dup && !has_long && !gathered_instead && max_ncam >= 1 && max_ncam <= 32 &&
+                          6 * max_ncam <= kSmallMaxN;
   pairs_total = ((pairs_total + 7) & ~7ll) + 8;              // whole-uint4 reads of the last list stay inside
-  pairs.assign((size_t)pairs_total, kPairPad);
+  pairs.assign(dest_owned ? 8 : (size_t)pairs_total, kPairPad);
   // plain generation order (landmark by landmark, i then j): the gathered mode and the sorting fallback start from it.
   // A pair (i, j), i < j, of two DIFFERENT poses goes to an off-diagonal block of the reduced matrix, of which only
   // the upper one is kept; two observations of the SAME pose both go to its diagonal block, which needs
@@ -780,7 +790,7 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   // the reduced matrix once ------------------------------------------------------------------------
   std::vector<RunDesc> runs;
   const long long n_dest_max = (long long)max_ncam * (max_ncam + 1) / 2;
-  if (!staged && n_blk_pm > 0) {
+  if (!staged && !dest_owned && n_blk_pm > 0) {
     // a keyframe window has ~10^5 pairs: worth four short-lived threads (grouping them is the longest host step
     // of hipba_solve); large problems use up to sixteen
     const int n_thr = (int)std::min<size_t>(std::max(1u, std::min(16u, std::thread::hardware_concurrency())),
@@ -1018,6 +1028,7 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   P.blocks = d_blocks; P.pairs = d_pairs; P.wd = d_wd; P.runs = d_runs;
   P.pair_obs = d_pair_obs; P.pair_pt = d_pair_pt; P.chunk_start = d_chunk_start;
   P.n_chunks = staged ? (int)(chunk_start.size() / 2) : 0;
+  P.dest_owned = dest_owned ? 1 : 0;
   if (!staged) { P.prec = nullptr; P.fw = nullptr; P.cam_tab = nullptr; }
 
   char* st = static_cast<char*>(h->staging);

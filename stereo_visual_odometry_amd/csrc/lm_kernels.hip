@@ -496,9 +496,22 @@ __device__ __forceinline__ void pair_products(const unsigned short* pairs, const
 //   parts-th block of the window; b is accumulated in LDS and flushed once per workgroup, and so is the
 //   whole packed S when it fits (MODE 1; MODE 3 sends S to HBM with atomics).  With S in LDS a lane forms whole
 //   products (one run each) instead of sharing one with eleven others: a third of the LDS bytes read per multiply-add.
+// MODE 4 (small windows, owned destinations): no pair or run lists at all.  A lane owns one 6x6 block (s_i, s_j) of the
+//   window's packed S for the whole launch and keeps it in 36 registers; for every landmark of a block it looks up
+//   whether poses s_i and s_j both observe it (one broadcast LDS read: the landmark's mask of observing slots and
+//   the lane of its first variable observation -- a segment is sorted by slot, so the observation of slot s sits
+//   popcount(mask below s) lanes further) and adds Z_i Z_j^T.  Nothing is added atomically inside the loop; the
+//   registers go to S once at the end.  Windows of few poses (at most 128 blocks in S) split a block's landmarks
+//   over several lane groups per destination and sum the groups in LDS first; windows of more than 22 poses (more
+//   than 256 blocks) are covered by several workgroups per part, each repeating the cheap phases 1 and 2 and owning
+//   its 256 destinations.  Needs: no pose observing a landmark twice, at most 32 poses (the mask).
+constexpr int kOwnedSplitBlocks = 128;  // windows of at most this many blocks in S: several lane groups per block
+
 template <int MODE>
-__device__ __forceinline__ void point_schur_body(const DevP& P, const LmParams& lm, int parts, const int bid) {
-  constexpr bool SMALL = MODE == 1 || MODE == 3;
+__device__ __forceinline__ void point_schur_body(const DevP& P, const LmParams& lm, int parts, const int bid,
+                                                 const int dgroups = 1) {
+  constexpr bool OWNED = MODE == 4;
+  constexpr bool SMALL = MODE == 1 || MODE == 3 || OWNED;
   constexpr bool LDS_S = MODE == 1;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int kStage = MODE == 2 ? 9 : kYW;  // gathered mode stages only the phase-1 words
@@ -507,15 +520,19 @@ __device__ __forceinline__ void point_schur_body(const DevP& P, const LmParams& 
   double* red = smem + kBlock * kStage + kBlock / 2;            // [8]
   unsigned short* sPairs = reinterpret_cast<unsigned short*>(red + 8);   // [kLdsPairs] (not in staged mode)
   RunDesc* sRuns = reinterpret_cast<RunDesc*>(sPairs + kLdsPairs);      // [kLdsRuns]
-  double* accB = reinterpret_cast<double*>(sRuns + kLdsRuns);           // SMALL: b, then (LDS_S) packed S
+  uint2* sLm = reinterpret_cast<uint2*>(red + 8);                       // OWNED (instead of the lists): [kBlock] (mask, first lane)
+  double* accB = OWNED ? reinterpret_cast<double*>(sLm + kBlock)
+                       : reinterpret_cast<double*>(sRuns + kLdsRuns);   // SMALL: b, then (LDS_S, OWNED) packed S
   double* accS = accB + kSmallMaxN;
 
   const int t = threadIdx.x;
   HIPBA_TICK(0);
-  int blk = bid, blk_end = bid + 1, blk_step = 1, w;
+  int blk = bid, blk_end = bid + 1, blk_step = 1, w, dg = 0;
   if (SMALL) {
-    w = bid / parts;
-    const int part = bid - w * parts;
+    const int wp = OWNED ? bid / dgroups : bid;
+    if (OWNED) dg = bid - wp * dgroups;
+    w = wp / parts;
+    const int part = wp - w * parts;
     blk = P.wd[w].pm_blk_begin + part;
     blk_end = P.wd[w].pm_blk_end;
     blk_step = parts;
@@ -528,10 +545,31 @@ __device__ __forceinline__ void point_schur_body(const DevP& P, const LmParams& 
   const WinDesc wd = P.wd[w];
   const int sel = st->sel;
   const double inv_radius = 1.0 / st->radius;
-  const int nS = LDS_S ? (wd.ncam * (wd.ncam + 1) / 2) * 36 : 0;
+  // owned destinations: this lane's block (own_i, own_j) of S, and which of the own_k lane groups of that block it is
+  const int ndest = wd.ncam * (wd.ncam + 1) / 2;
+  int own_i = 0, own_j = 0, own_sub = 0, own_k = 1, own_dest = 0;
+  bool own = false;
+  if (OWNED) {
+    if (dg > 0 && dg * kBlock >= ndest) return;  // (a window of fewer poses than the launch was sized for)
+    if (ndest == 0) { own = false; }  // (every pose constant: the landmark quantities are still formed)
+    else if (ndest <= kOwnedSplitBlocks) { own_k = kBlock / ndest; own_sub = t / ndest; own_dest = t - own_sub * ndest; own = own_sub < own_k; }
+    else { own_dest = dg * kBlock + t; own = own_dest < ndest; }
+    if (own) {
+      int rem = own_dest;
+      while (rem >= wd.ncam - own_i) { rem -= wd.ncam - own_i; ++own_i; }
+      own_j = own_i + rem;
+    }
+  }
+  double own_acc[OWNED ? 36 : 1];
+#pragma unroll
+  for (int i = 0; i < (OWNED ? 36 : 1); ++i) own_acc[i] = 0.0;
+  // what goes to S from LDS at the end: the whole packed matrix (MODE 1), this workgroup's destinations (MODE 4)
+  const int own_base = OWNED ? dg * kBlock : 0;
+  const int nS = LDS_S ? ndest * 36 : OWNED ? max(0, min(ndest - own_base, kBlock)) * 36 : 0;
+  const int nS_zero = (LDS_S || own_k > 1) ? nS : 0;
   if (SMALL) {
     for (int i = t; i < 6 * wd.ncam; i += kBlock) accB[i] = 0.0;
-    for (int i = t; i < nS; i += kBlock) accS[i] = 0.0;
+    for (int i = t; i < nS_zero; i += kBlock) accS[i] = 0.0;
   }
   double gmax = 0.0, g2 = 0.0;
   const int first_blk = blk;
@@ -541,9 +579,15 @@ __device__ __forceinline__ void point_schur_body(const DevP& P, const LmParams& 
     if (MODE == 2 && d.pad) return;  // a piece of a long landmark (gathered mode only): k_long_point's
     if (SMALL) __syncthreads();  // accumulators zeroed / previous block's products read
     HIPBA_TICK(1);
+    int pp0 = 0, n_lm = 0;
+    if (OWNED) {
+      pp0 = P.obs_dp[d.obs_begin];
+      n_lm = P.obs_dp[d.obs_begin + d.n_obs - 1] - pp0 + 1;  // (consecutive landmarks, at least one observation each)
+      sLm[t] = make_uint2(0u, 0xffffffffu);
+    }
     // the block's pair and run lists go to LDS when they fit; the loads are issued here, ahead of the
     // observation work, and land in LDS together with Y and W
-    const bool lists_in_lds = MODE != 2 && d.n_pairs <= kLdsPairs && d.n_runs <= kLdsRuns;
+    const bool lists_in_lds = MODE != 2 && !OWNED && d.n_pairs <= kLdsPairs && d.n_runs <= kLdsRuns;
     // (native vector types, named one by one: an array of HIP's uint4 class is not promoted to registers -- it sat in
     // scratch, and every one of these loads waited for its own round trip to memory before the next was issued)
     typedef unsigned int v4u __attribute__((ext_vector_type(4)));
@@ -605,7 +649,7 @@ __device__ __forceinline__ void point_schur_body(const DevP& P, const LmParams& 
       V[5] += fmin(fmax(V[5], lm.min_lm_diagonal), lm.max_lm_diagonal) * inv_radius;
       double Vi[6];
       inv3_sym(V, Vi);
-      if (t == s0) {
+      if (t == s0 && dg == 0) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) P.Vinv[6ll * pp + i] = Vi[i];
 #pragma unroll
@@ -652,7 +696,7 @@ __device__ __forceinline__ void point_schur_body(const DevP& P, const LmParams& 
           Z[3 * i + 2] = w2 * c22;
         }
         // b_c -= Y g_p = Z (C^T g_p) (gathered mode leaves this to k_schur_gather: one writer per pose instead of atomics)
-        if (MODE != 2) {
+        if (MODE != 2 && dg == 0) {
           const double u0 = c00 * gpv[0] + c10 * gpv[1] + c20 * gpv[2], u1 = c11 * gpv[1] + c21 * gpv[2], u2 = c22 * gpv[2];
           double* bdst = SMALL ? accB + 6 * slot : P.b + 6ll * (wd.cam_base + slot);
 #pragma unroll
@@ -677,13 +721,36 @@ __device__ __forceinline__ void point_schur_body(const DevP& P, const LmParams& 
         double* z = sYW + kYW * t;
 #pragma unroll
         for (int i = 0; i < 18; ++i) z[i] = Z[i];
+        if (OWNED) {
+          atomicOr(&sLm[pp - pp0].x, 1u << slot);
+          atomicMin(&sLm[pp - pp0].y, (unsigned)t);
+        }
       }
     }
     __syncthreads();
     HIPBA_TICK(4);
+    if (OWNED && own) {
+      const unsigned bit_i = 1u << own_i, bit_j = 1u << own_j;
+      for (int l = own_sub; l < n_lm; l += own_k) {
+        const uint2 m = sLm[l];
+        if ((m.x & bit_i) && (m.x & bit_j)) {
+          const double* Zi = sYW + kYW * (m.y + __popc(m.x & (bit_i - 1)));
+          const double* Zj = sYW + kYW * (m.y + __popc(m.x & (bit_j - 1)));
+          double zj[18];
+#pragma unroll
+          for (int ii = 0; ii < 18; ++ii) zj[ii] = Zj[ii];
+#pragma unroll
+          for (int a = 0; a < 6; ++a) {
+            const double y0 = Zi[3 * a], y1 = Zi[3 * a + 1], y2 = Zi[3 * a + 2];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) own_acc[6 * a + c] -= y0 * zj[3 * c] + y1 * zj[3 * c + 1] + y2 * zj[3 * c + 2];
+          }
+        }
+      }
+    }
 
     // phase 3: pair products (staged mode: every product to its own slot; otherwise run by run)
-    if (MODE != 2) {
+    if (MODE != 2 && !OWNED) {
       double* Sbase = LDS_S ? accS : P.S + wd.S_off;
       if (lists_in_lds) pair_products<!LDS_S>(sPairs, sRuns, d.n_runs, sYW, Sbase, t);
       else pair_products<!LDS_S>(P.pairs + d.pair_begin, P.runs + d.run_begin, d.n_runs, sYW, Sbase, t);
@@ -696,7 +763,7 @@ __device__ __forceinline__ void point_schur_body(const DevP& P, const LmParams& 
   gmax = block_max(gmax, red);
   double gs[1] = {g2};
   block_sum<1>(gs, red);
-  if (t == 0) {
+  if (t == 0 && dg == 0) {
     P.gpart[2ll * first_blk + 0] = gmax;
     P.gpart[2ll * first_blk + 1] = gs[0];
     if (SMALL) {
@@ -707,9 +774,23 @@ __device__ __forceinline__ void point_schur_body(const DevP& P, const LmParams& 
     }
   }
   HIPBA_TICK(6);
+  if (OWNED && own) {
+    // the lane's block of S goes to LDS (several lane groups per block: summed there), so that the sweep below adds
+    // it to S with neighbouring lanes on neighbouring words -- a lane adding its own 36 words would make every
+    // one of them a memory request of its own
+    double* dst = accS + 36 * (own_dest - own_base);
+    if (own_k > 1) {
+#pragma unroll
+      for (int a = 0; a < 36; ++a)
+        if (own_acc[a] != 0.0) atomic_add_f64(dst + a, own_acc[a]);
+    } else {
+#pragma unroll
+      for (int a = 0; a < 36; ++a) dst[a] = own_acc[a];
+    }
+  }
   if (SMALL) {
     __syncthreads();
-    double* Sg = P.S + wd.S_off;
+    double* Sg = P.S + wd.S_off + 36ll * own_base;
     for (int i = t; i < nS; i += kBlock) {
       const double v = accS[i];
       if (v != 0.0) atomic_add_f64(Sg + i, v);
@@ -734,14 +815,18 @@ __global__ __launch_bounds__(kBlock) void k_point_schur(DevP P, LmParams lm, int
 // pass before leaves them so).  Both halves are a few dozen workgroups of a few microseconds' dependent work: side
 // by side on the chip they cost the longer of the two, and one launch boundary less.
 template <int MODE>
-__global__ __launch_bounds__(kBlock) void k_small_linearize(DevP P, LmParams lm, int parts) {
-  static_assert(MODE == 1 || MODE == 3, "small-window modes only");
+__global__ __launch_bounds__(kBlock) void k_small_linearize(DevP P, LmParams lm, int parts, int dgroups) {
+  static_assert(MODE == 1 || MODE == 3 || MODE == 4, "small-window modes only");
   if ((int)blockIdx.x < P.n_act_poses) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     camera_blocks_body(P, lm, blockIdx.x, 1, 2, smem);
   } else {
-    point_schur_body<MODE>(P, lm, parts, (int)blockIdx.x - P.n_act_poses);
+    point_schur_body<MODE>(P, lm, parts, (int)blockIdx.x - P.n_act_poses, dgroups);
   }
+}
+
+__global__ __launch_bounds__(kBlock) void k_point_schur_owned(DevP P, LmParams lm, int parts, int dgroups) {
+  point_schur_body<4>(P, lm, parts, blockIdx.x, dgroups);
 }
 
 // gathered mode: S(block d) -= sum over its observation pairs of Y_i W_j^T.  A wave owns a chunk of the
@@ -2197,6 +2282,19 @@ __global__ void k_count_active(DevP P, int* out) {
 // ------------------------------------------------------------------------------------------
 // LDS of k_point_schur: Y/W staging, slots, reduction words; outside staged mode the block's pair and run
 // lists; the small-window modes add b and, up to kLdsSMaxCam poses, the packed S
+// the owned-destination mode: Z staging, slots, reduction words, the landmark table, b, and the workgroup's 256
+// blocks of S
+size_t schur_owned_lds_bytes(int small_ncam) {
+  const size_t ndest = (size_t)small_ncam * (small_ncam + 1) / 2;
+  return (size_t)kBlock * kYW * 8 + (size_t)kBlock * 4 + 8 * 8 + (size_t)kBlock * 8 + (size_t)kSmallMaxN * 8 +
+         std::min<size_t>(ndest, kBlock) * 36 * 8;
+}
+// workgroups per part in that mode: 256 destinations each
+static int owned_dest_groups(int small_ncam) {
+  const int ndest = small_ncam * (small_ncam + 1) / 2;
+  return (ndest + kBlock - 1) / kBlock;
+}
+
 size_t schur_lds_bytes(int small_ncam, bool staged) {
   size_t base = (size_t)kBlock * (staged ? 9 : kYW) * 8 + (size_t)kBlock * 4 + 8 * 8;
   if (!staged) base += (size_t)kLdsPairs * 2 + (size_t)kLdsRuns * sizeof(RunDesc);
@@ -2212,7 +2310,8 @@ size_t schur_lds_bytes(int small_ncam, bool staged) {
 hipError_t configure_lm_kernels() {
   const void* big[] = {reinterpret_cast<const void*>(&k_point_schur<0>), reinterpret_cast<const void*>(&k_point_schur<1>),
                        reinterpret_cast<const void*>(&k_point_schur<2>), reinterpret_cast<const void*>(&k_point_schur<3>),
-                       reinterpret_cast<const void*>(&k_small_linearize<1>), reinterpret_cast<const void*>(&k_small_linearize<3>)};
+                       reinterpret_cast<const void*>(&k_small_linearize<1>), reinterpret_cast<const void*>(&k_small_linearize<3>),
+                       reinterpret_cast<const void*>(&k_small_linearize<4>), reinterpret_cast<const void*>(&k_point_schur_owned)};
   for (const void* f : big) {
     const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
@@ -2270,6 +2369,11 @@ hipError_t launch_point_schur(const DevP& P, const LmParams& lm, int small_ncam,
     const size_t gather_lds = (size_t)(kBlock / 64) * kGatherLds * 8;
     const unsigned grid = (unsigned)((P.n_chunks + kBlock / 64 - 1) / (kBlock / 64));
     if (grid) hipLaunchKernelGGL(k_schur_gather, dim3(grid), dim3(kBlock), gather_lds, s, P, lm);
+  } else if (small_ncam > 0 && P.dest_owned) {
+    if (parts < 1) parts = 1;
+    const int dgroups = owned_dest_groups(small_ncam);
+    hipLaunchKernelGGL(k_point_schur_owned, dim3((unsigned)P.n_windows * (unsigned)parts * (unsigned)dgroups), dim3(kBlock),
+                       schur_owned_lds_bytes(small_ncam), s, P, lm, parts, dgroups);
   } else if (small_ncam > 0) {
     if (parts < 1) parts = 1;
     const size_t lds = schur_lds_bytes(small_ncam, false);
@@ -2289,12 +2393,16 @@ hipError_t launch_point_schur(const DevP& P, const LmParams& lm, int small_ncam,
 hipError_t launch_small_linearize(const DevP& P, const LmParams& lm, int small_ncam, int parts, hipStream_t s) {
   if (small_ncam <= 0 || P.n_act_poses <= 0 || P.prec) return hipErrorInvalidValue;
   if (parts < 1) parts = 1;
-  const size_t lds = schur_lds_bytes(small_ncam, false);  // (the camera half needs 27 * 4 doubles of it)
-  const unsigned grid = (unsigned)P.n_act_poses + (P.n_blk_pm > 0 ? (unsigned)P.n_windows * (unsigned)parts : 0u);
-  if (small_ncam <= kLdsSMaxCam)
-    hipLaunchKernelGGL(k_small_linearize<1>, dim3(grid), dim3(kBlock), lds, s, P, lm, parts);
+  const int dgroups = P.dest_owned ? owned_dest_groups(small_ncam) : 1;
+  // (the camera half needs 27 * 4 doubles of the LDS)
+  const size_t lds = P.dest_owned ? schur_owned_lds_bytes(small_ncam) : schur_lds_bytes(small_ncam, false);
+  const unsigned grid = (unsigned)P.n_act_poses + (P.n_blk_pm > 0 ? (unsigned)P.n_windows * (unsigned)parts * (unsigned)dgroups : 0u);
+  if (P.dest_owned)
+    hipLaunchKernelGGL(k_small_linearize<4>, dim3(grid), dim3(kBlock), lds, s, P, lm, parts, dgroups);
+  else if (small_ncam <= kLdsSMaxCam)
+    hipLaunchKernelGGL(k_small_linearize<1>, dim3(grid), dim3(kBlock), lds, s, P, lm, parts, 1);
   else
-    hipLaunchKernelGGL(k_small_linearize<3>, dim3(grid), dim3(kBlock), lds, s, P, lm, parts);
+    hipLaunchKernelGGL(k_small_linearize<3>, dim3(grid), dim3(kBlock), lds, s, P, lm, parts, 1);
   return hipGetLastError();
 }
 
