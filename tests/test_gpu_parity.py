@@ -247,13 +247,15 @@ def test_edge_cases(solver, oracle):
     assert_logs_match(s["iterations"], oits)
 
 
-@pytest.mark.parametrize("scene", ["small_lds", "window_atomics", "gathered"])
+@pytest.mark.parametrize("scene", ["small_lds", "small_b_in_lds", "window_atomics", "gathered"])
 def test_repeated_observations_of_a_landmark_by_one_pose(solver, oracle, scene):
     """Two residual blocks on the same (pose, landmark) pair are legal in ceres::Problem (optimizer.cpp:47-50 adds one
     per feature).  Their cross term lands on the DIAGONAL block of the reduced matrix, which needs the product in both
     orders: an error there still converges, so the per-iteration log is compared, in every accumulation mode."""
     if scene == "small_lds":
         prob, _, _ = scenes.small_window(4207, n_frames=8, n_points=300)
+    elif scene == "small_b_in_lds":
+        prob, _, _ = scenes.small_window(4209, n_frames=28, n_points=400)   # 27 variable poses: pair lists, S in HBM
     elif scene == "window_atomics":
         prob, _, _ = scenes.small_window(4208, n_frames=36, n_points=500)   # 35 variable poses: fp64 atomics into HBM
     else:
@@ -702,10 +704,13 @@ def _check_against_oracle(oracle, prob, gpu_prob, summary, loss=None, loss_scale
     assert_logs_match(summary["iterations"], oits)
 
 
-@pytest.mark.parametrize("n_frames", [2, 3, 7, 21, 22, 23, 32, 33])
+@pytest.mark.parametrize("n_frames", [2, 3, 7, 16, 17, 21, 22, 23, 24, 32, 33])
 def test_window_sizes_across_the_accumulation_modes(solver, oracle, n_frames):
-    """Window sizes on both sides of every switch in the elimination kernels: whole S in LDS (<= 21 variable
-    poses), b only in LDS (<= 32), atomics into HBM with the large-matrix solver (33+)."""
+    """Window sizes on both sides of every switch in the elimination kernels.  Windows the LDS solver takes (<= 32
+    variable poses) let every lane own one block of S: several lane groups per block up to 128 blocks (15 poses), one
+    workgroup per part up to 256 blocks (22 poses), two or three beyond; 33+ poses go to atomics into HBM with the
+    large-matrix solver.  (With a pose observing a landmark twice the same sizes take the pair lists instead: whole S
+    in LDS up to 21 poses, b only up to 32 -- test_repeated_observations_of_a_landmark_by_one_pose.)"""
     prob, _, _ = scenes.small_window(4000 + n_frames, n_frames=n_frames, n_points=600)
     g = prob.copy()
     s = solver.solve(g, hipba.reference_production_options())
