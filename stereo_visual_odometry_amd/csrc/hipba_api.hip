@@ -92,6 +92,22 @@ class HostWorkers {
     job_ = nullptr;
     return !failed_;
   }
+  // f(1) on a worker while the caller goes on; f must stay alive until wait() has returned.  No other job in between.
+  void start(const std::function<void(int)>& f) {
+    failed_ = false;
+    if (threads_.empty()) threads_.emplace_back([this] { loop(1); });
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      job_ = &f; parts_ = 2; pending_ = 1; ++generation_;
+    }
+    go_.notify_all();
+  }
+  bool wait() {
+    std::unique_lock<std::mutex> lk(m_);
+    done_.wait(lk, [this] { return pending_ == 0; });
+    job_ = nullptr;
+    return !failed_;
+  }
 
  private:
   void call(const std::function<void(int)>& f, int i) {
@@ -195,7 +211,6 @@ struct hipba_device_problem_s {
   std::vector<WinMeta> meta;
   double* poses0 = nullptr;   // uploaded parameters, kept for hipba_reset
   double* points0 = nullptr;
-  int* d_count = nullptr;
   int max_ncam = 0;
   int max_pm_blocks = 0;      // most PM blocks in one window
   long long upload_bytes = 0; // host-to-device bytes of the upload
@@ -308,7 +323,7 @@ LmParams make_lm(const hipba_options& o) {
   return lm;
 }
 
-int validate_problem(const hipba_problem& p, int w) {
+int validate_problem(const hipba_problem& p, int w, bool check_indices = true) {
   if (p.n_poses < 0 || p.n_points < 0 || p.n_obs < 0) return fail(HIPBA_ERR_INVALID_ARGUMENT, "window %d: negative size", w);
   if ((p.n_poses && !p.poses) || (p.n_points && !p.points))
     return fail(HIPBA_ERR_INVALID_ARGUMENT, "window %d: null parameter array", w);
@@ -316,7 +331,7 @@ int validate_problem(const hipba_problem& p, int w) {
     return fail(HIPBA_ERR_INVALID_ARGUMENT, "window %d: null observation array", w);
   if (p.camera_model != HIPBA_CAMERA_Z_FORWARD && p.camera_model != HIPBA_CAMERA_X_FORWARD)
     return fail(HIPBA_ERR_INVALID_ARGUMENT, "window %d: unknown camera model %d", w, p.camera_model);
-  for (long long k = 0; k < p.n_obs; ++k) {
+  for (long long k = 0; check_indices && k < p.n_obs; ++k) {
     if (p.obs_pose[k] < 0 || p.obs_pose[k] >= p.n_poses || p.obs_point[k] < 0 || p.obs_point[k] >= p.n_points)
       return fail(HIPBA_ERR_INVALID_ARGUMENT, "window %d: observation %lld references pose %d / landmark %d out of range",
                   w, k, p.obs_pose[k], p.obs_point[k]);
@@ -345,7 +360,7 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
                    bool all_poses_active, hipba_device_problem_s** out, const int32_t* pose_order = nullptr) {
   SETUP_CLOCK();
   for (int w = 0; w < nw; ++w) {
-    int rc = validate_problem(probs[w], w);
+    int rc = validate_problem(probs[w], w, /*check_indices=*/false);  // (the indices: in the counting pass below)
     if (rc) return rc;
   }
   // owned here until handed to the caller: every early return and every exception releases it (and its arena)
@@ -372,14 +387,25 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   std::vector<int> deg(NPT, 0);          // observations of a variable landmark
   std::vector<int> pose_nobs(NP, 0);
   std::vector<uint8_t> pose_c(NP, 0), pt_c(NPT, 0);
+  long long n_vc = 0, n_cc = 0;
   for (int w = 0; w < nw; ++w) {
     const hipba_problem& p = probs[w];
     for (int i = 0; i < p.n_poses; ++i) pose_c[R->meta[w].pose_base + i] = p.pose_const ? (p.pose_const[i] != 0) : 0;
     for (int i = 0; i < p.n_points; ++i) pt_c[pt_base[w] + i] = p.point_const ? (p.point_const[i] != 0) : 0;
+    // one pass: the indices checked, observations per variable landmark and per pose, and the sizes of the two
+    // sections of observations of constant landmarks (variable pose / constant pose)
+    const unsigned np_w = (unsigned)p.n_poses, npt_w = (unsigned)p.n_points;
+    const int pose_base = R->meta[w].pose_base;
     for (long long k = 0; k < p.n_obs; ++k) {
-      const long long gp = pt_base[w] + p.obs_point[k];
+      const unsigned ip = (unsigned)p.obs_pose[k], iq = (unsigned)p.obs_point[k];
+      if (ip >= np_w || iq >= npt_w)
+        return fail(HIPBA_ERR_INVALID_ARGUMENT, "window %d: observation %lld references pose %d / landmark %d out of range",
+                    w, k, p.obs_pose[k], p.obs_point[k]);
+      const long long gp = pt_base[w] + iq;
       if (!pt_c[gp]) deg[gp]++;
-      pose_nobs[R->meta[w].pose_base + p.obs_pose[k]]++;
+      else if (pose_c[pose_base + ip]) ++n_cc;
+      else ++n_vc;
+      pose_nobs[pose_base + ip]++;
     }
   }
   // device landmark order: variable observed landmarks first (by window, index), the rest after
@@ -434,22 +460,55 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   }
 
   SETUP_MARK("counts");
+  // ---- camera-major lists and the parameters in device order -----------------------------------------
+  // Straight from the caller's arrays (every observation by a variable pose, in the caller's order), so they depend
+  // on nothing below but the slots: for windows whose slots are final here (not the one large window whose poses are
+  // reordered further down) a worker of the handle builds them while this thread sorts the observations by landmark.
+  std::vector<long long> cm_start(n_slots + 1, 0);
+  std::vector<int> cm_dp;
+  std::vector<double> cm_uv;
+  std::vector<double> poses(std::max<long long>(7 * NP, 7)), points(std::max<long long>(3 * NPT, 3));
+  auto build_side_lists = [&]() {
+    for (int g = 0; g < n_slots; ++g) cm_start[g + 1] = pose_nobs[slot_pose[g]];
+    for (int g = 0; g < n_slots; ++g) cm_start[g + 1] += cm_start[g];
+    const long long n_cm = cm_start[n_slots];
+    cm_dp.resize(std::max<long long>(n_cm, 1));
+    cm_uv.resize(std::max<long long>(2 * n_cm, 2));
+    std::vector<long long> cur(cm_start.begin(), cm_start.end() - 1);
+    for (int w = 0; w < nw; ++w) {
+      const hipba_problem& p = probs[w];
+      const int pose_base = R->meta[w].pose_base;
+      for (long long k = 0; k < p.n_obs; ++k) {
+        const int g = pose_gslot[pose_base + p.obs_pose[k]];
+        if (g < 0) continue;
+        const long long dst = cur[g]++;
+        cm_dp[dst] = dp_of[pt_base[w] + p.obs_point[k]];
+        cm_uv[2 * dst] = p.obs_uv[2 * k]; cm_uv[2 * dst + 1] = p.obs_uv[2 * k + 1];
+      }
+      if (p.n_poses) memcpy(poses.data() + 7ll * pose_base, p.poses, sizeof(double) * 7 * p.n_poses);
+      for (int i = 0; i < p.n_points; ++i) {
+        const int dp = dp_of[pt_base[w] + i];
+        points[3ll * dp] = p.points[3 * i]; points[3ll * dp + 1] = p.points[3 * i + 1]; points[3ll * dp + 2] = p.points[3 * i + 2];
+      }
+    }
+  };
+  const std::function<void(int)> side_lists_job = [&](int) { build_side_lists(); };
+  bool side_lists_async = false;
+  // (joins the worker on every way out of this function: it works on this frame's vectors)
+  struct JoinWorker {
+    HostWorkers& w; bool& active;
+    ~JoinWorker() { if (active) (void)w.wait(); }
+  } join_worker{h->workers, side_lists_async};
+  if (!(nw == 1 && 6 * max_ncam > kSmallMaxN) && n_slots > 0) {
+    h->workers.start(side_lists_job);
+    side_lists_async = true;
+  }
   // ---- observations: PM | VC | CC --------------------------------------------------------------
   std::vector<long long> pp_start(n_pm_points + 1, 0);
   for (long long gp = 0; gp < NPT; ++gp)
     if (deg[gp] > 0) pp_start[dp_of[gp] + 1] = deg[gp];
   for (int i = 0; i < n_pm_points; ++i) pp_start[i + 1] += pp_start[i];
   const long long n_pm_obs = pp_start[n_pm_points];
-  long long n_vc = 0, n_cc = 0;
-  for (int w = 0; w < nw; ++w) {
-    const hipba_problem& p = probs[w];
-    for (long long k = 0; k < p.n_obs; ++k) {
-      const long long gp = pt_base[w] + p.obs_point[k];
-      if (pt_c[gp]) {
-        if (pose_c[R->meta[w].pose_base + p.obs_pose[k]]) ++n_cc; else ++n_vc;
-      }
-    }
-  }
   const long long n_act_obs = n_pm_obs + n_vc, n_all = n_act_obs + n_cc;
   std::vector<int> obs_pose(std::max<long long>(n_all, 1)), obs_dp(std::max<long long>(n_all, 1));
   std::vector<double> obs_uv(std::max<long long>(2 * n_all, 2));
@@ -747,43 +806,13 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   }
 
   SETUP_MARK("gathered lists");
-  // ---- camera-major lists and the parameters in device order -----------------------------------------
-  // Independent of the run lists below: on small windows the caller's thread builds them while the handle's workers
-  // group the pairs (what used to be two steps one after the other).
-  std::vector<long long> cm_start(n_slots + 1, 0);
-  std::vector<int> cm_dp;
-  std::vector<double> cm_uv;
-  std::vector<double> poses(std::max<long long>(7 * NP, 7)), points(std::max<long long>(3 * NPT, 3));
-  bool side_lists_done = false;
-  auto build_side_lists = [&]() {
-    for (long long o = 0; o < n_act_obs; ++o) {
-      const int g = pose_gslot[obs_pose[o]];
-      if (g >= 0) cm_start[g + 1]++;
-    }
-    for (int g = 0; g < n_slots; ++g) cm_start[g + 1] += cm_start[g];
-    const long long n_cm = cm_start[n_slots];
-    cm_dp.resize(std::max<long long>(n_cm, 1));
-    cm_uv.resize(std::max<long long>(2 * n_cm, 2));
-    {
-      std::vector<long long> cur(cm_start.begin(), cm_start.end() - 1);
-      for (long long o = 0; o < n_act_obs; ++o) {
-        const int g = pose_gslot[obs_pose[o]];
-        if (g < 0) continue;
-        const long long dst = cur[g]++;
-        cm_dp[dst] = obs_dp[o];
-        cm_uv[2 * dst] = obs_uv[2 * o]; cm_uv[2 * dst + 1] = obs_uv[2 * o + 1];
-      }
-    }
-    for (int w = 0; w < nw; ++w) {
-      const hipba_problem& p = probs[w];
-      if (p.n_poses) memcpy(poses.data() + 7ll * R->meta[w].pose_base, p.poses, sizeof(double) * 7 * p.n_poses);
-      for (int i = 0; i < p.n_points; ++i) {
-        const int dp = dp_of[pt_base[w] + i];
-        points[3ll * dp] = p.points[3 * i]; points[3ll * dp + 1] = p.points[3 * i + 1]; points[3ll * dp + 2] = p.points[3 * i + 2];
-      }
-    }
-    side_lists_done = true;
-  };
+  // the camera-major lists: built meanwhile by a worker (small windows), or here now that the slots are final
+  if (side_lists_async) {
+    side_lists_async = false;
+    if (!h->workers.wait()) return fail(HIPBA_ERR_OUT_OF_MEMORY, "host analysis of the camera-major lists ran out of memory");
+  } else {
+    build_side_lists();
+  }
 
   // ---- atomic / LDS accumulation: each block's pair list grouped by destination block and cut into runs
   // of at most kRunMax pairs with one destination; a lane group sums a run in registers and adds it to
@@ -885,9 +914,8 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
     if (n_thr <= 1) {
       group_range(0, 0, n_blk_pm);
     } else if (n_thr <= 8) {
-      // the handle's sleeping workers take the blocks; the caller's thread (part 0 of the job) builds the camera-major
-      // lists and the device-order parameters meanwhile
-      if (!h->workers.run(n_thr + 1, [&](int i) { if (i == 0) build_side_lists(); else group_range(i - 1, lo(i - 1), lo(i)); }))
+      // the handle's sleeping workers (and this thread) take the blocks
+      if (!h->workers.run(n_thr, [&](int i) { group_range(i, lo(i), lo(i + 1)); }))
         return fail(HIPBA_ERR_OUT_OF_MEMORY, "host analysis of the pair lists ran out of memory");
     } else {
       // short-lived threads for a large problem; an exception of a part stays inside its thread, and a thread that
@@ -924,8 +952,6 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   }
 
   SETUP_MARK("runs");
-  // ---- camera-major lists, parameters in device order: built by build_side_lists above, beside the run lists -----
-  if (!side_lists_done) build_side_lists();
   for (int w = 0; w < nw; ++w) {
     long long na = 0;
     for (int b = wd[w].pm_blk_begin; b < wd[w].pm_blk_end; ++b) na += blocks[b].n_obs;
@@ -993,7 +1019,6 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   work.add(&P.gpart, (size_t)2 * std::max(n_blk_pm, 1));
   work.add(&P.wsum, (size_t)8 * nw);
   work.add(&P.log, (size_t)std::max(log_cap, 1) * nw);
-  work.add(&R->d_count, 4);
   if (staged) { work.add(&P.prec, 16 * npp); work.add(&P.fw, (size_t)n_pm_obs); work.add(&P.cam_tab, 18 * ns); }
   char* big_base_dummy = nullptr;
   size_t big_bytes = 0;
@@ -1334,7 +1359,7 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
       HIPBA_HIP(launch_window_control(P, lm, kDecide, nullptr, 0, s));
     } else {
       // a single window reports "still active" itself; batches are counted by k_count_active below
-      HIPBA_HIP(launch_window_control(P, lm, kFused, P.n_windows == 1 ? R->d_count + (iter & 3) : nullptr, control_zeroes_S ? 1 : 0, s));
+      HIPBA_HIP(launch_window_control(P, lm, kFused, P.n_windows == 1 ? h->h_count + (iter & 3) : nullptr, control_zeroes_S ? 1 : 0, s));
     }
     iterations_run = iter;
     // "windows still active" travels to the host through a ring of pinned words.  Small windows: the host looks
@@ -1342,8 +1367,9 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
     // iterations (every kernel returns at once for a window that has stopped; at most two idle iterations are
     // queued).  Large windows and big batches poll every iteration: an idle pass there is not free.
     const int slot = iter & 3;
-    if (sharded || P.n_windows != 1) HIPBA_HIP(launch_count_active(P, R->d_count + slot, s));
-    HIPBA_HIP(hipMemcpyAsync(h->h_count + slot, R->d_count + slot, sizeof(int), hipMemcpyDeviceToHost, s));
+    // (the kernels store the word straight into the pinned ring, which the device reaches at the same address: no
+    // copy is queued behind them)
+    if (sharded || P.n_windows != 1) HIPBA_HIP(launch_count_active(P, h->h_count + slot, s));
     HIPBA_HIP(hipEventRecord(h->poll_ev[slot], s));
     // (a window with a few thousand observations keeps the GPU busy for longer than the host needs to see a count
     // and queue a pass: one pass of lag is enough there and costs one idle pass at the end instead of two)
