@@ -227,6 +227,7 @@ struct hipba_device_problem_s {
   // parameter buffers, fetched with the solve's own final synchronisation so that reading the result back costs no
   // further round trip over the host link
   bool tail_valid = false;
+  size_t tail_span = 0;  // bytes from the start of the arena that hold both parameter buffers and the window states
   const WinState* tail_ws = nullptr;
   const double* tail_poses[2] = {nullptr, nullptr};
   const double* tail_points[2] = {nullptr, nullptr};
@@ -977,8 +978,14 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   double *d_cm_uv, *d_obs_uv;
   BlockDesc* d_blocks; unsigned short* d_pairs; WinDesc* d_wd; RunDesc* d_runs;
   uint2 *d_pair_obs = nullptr, *d_pair_pt = nullptr; long long* d_chunk_start = nullptr;
+  // parameters (both buffers) and the window states first and next to each other: they arrive with the upload (the
+  // candidate buffers as copies, the states as zeros) and leave in one copy at the end of a solve
   up.add(&P.poses[0], poses.size());
   up.add(&P.points[0], points.size());
+  up.add(&P.poses[1], poses.size());
+  up.add(&P.points[1], points.size());
+  up.add(&P.ws, (size_t)nw);
+  R->tail_span = up.total;
   up.add(&d_pose_window, std::max<size_t>(pose_window.size(), 1));
   up.add(&d_pose_gslot, std::max<size_t>(pose_gslot.size(), 1));
   up.add(&d_slot_pose, std::max<size_t>(slot_pose.size(), 1));
@@ -1001,11 +1008,8 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   ArenaPlan work = up;  // continues after the uploaded region
   work.items.clear();
   const size_t ns = std::max(n_slots, 1), npp = std::max(n_pm_points, 1);
-  work.add(&P.poses[1], poses.size());
-  work.add(&P.points[1], points.size());
   work.add(&R->poses0, poses.size());
   work.add(&R->points0, points.size());
-  work.add(&P.ws, (size_t)nw);
   work.add(&P.U, 36 * ns);
   work.add(&P.gc, 6 * ns);
   work.add(&P.scale_c, 6 * ns);
@@ -1062,6 +1066,9 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   };
   stage(P.poses[0], poses.data(), poses.size() * 8);
   stage(P.points[0], points.data(), points.size() * 8);
+  stage(P.poses[1], poses.data(), poses.size() * 8);
+  stage(P.points[1], points.data(), points.size() * 8);
+  memset(st + (reinterpret_cast<const char*>(P.ws) - static_cast<const char*>(R->arena)), 0, sizeof(WinState) * nw);
   stage(d_pose_window, pose_window.data(), pose_window.size() * 4);
   stage(d_pose_gslot, pose_gslot.data(), pose_gslot.size() * 4);
   stage(d_slot_pose, slot_pose.data(), slot_pose.size() * 4);
@@ -1086,13 +1093,10 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   hipStream_t s = h->stream;
   SETUP_MARK("fill staging");
   hipError_t e = hipMemcpyAsync(R->arena, h->staging, upload_bytes, hipMemcpyHostToDevice, s);
-  if (e == hipSuccess) e = hipMemcpyAsync(P.poses[1], P.poses[0], poses.size() * 8, hipMemcpyDeviceToDevice, s);
-  if (e == hipSuccess) e = hipMemcpyAsync(P.points[1], P.points[0], points.size() * 8, hipMemcpyDeviceToDevice, s);
   if (!use_handle_arena) {  // (a one-shot solve is never reset)
     if (e == hipSuccess) e = hipMemcpyAsync(R->poses0, P.poses[0], poses.size() * 8, hipMemcpyDeviceToDevice, s);
     if (e == hipSuccess) e = hipMemcpyAsync(R->points0, P.points[0], points.size() * 8, hipMemcpyDeviceToDevice, s);
   }
-  if (e == hipSuccess) e = hipMemsetAsync(P.ws, 0, sizeof(WinState) * nw, s);
   if (e == hipSuccess && R->has_big && !R->env_first.empty()) {
     R->env_first.push_back(0);  // the right-hand side's tile row is dense
     e = hipMemcpyAsync(R->big.first, R->env_first.data(), sizeof(int) * R->env_first.size(), hipMemcpyHostToDevice, s);
@@ -1386,32 +1390,27 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
   // summaries
   std::vector<WinState> ws(P.n_windows);
   R->tail_valid = false;
-  auto rup256 = [](size_t b) { return (b + 255) & ~(size_t)255; };
-  const size_t ws_bytes = rup256(sizeof(WinState) * (size_t)P.n_windows);
-  const size_t pose_bytes = rup256(sizeof(double) * 7 * (size_t)P.n_poses), point_bytes = rup256(sizeof(double) * 3 * (size_t)P.n_pm_points);
-  const size_t tail_bytes = ws_bytes + 2 * (pose_bytes + point_bytes);
-  bool tail = fetch_tail && tail_bytes <= ((size_t)1 << 20);
+  const size_t tail_bytes = R->tail_span;
+  bool tail = fetch_tail && tail_bytes > 0 && tail_bytes <= ((size_t)1 << 20);
   if (tail && h->staging_bytes < tail_bytes) {
     // the staging buffer has to grow: nothing queued may still be reading the old one (the upload came from it)
     HIPBA_HIP(hipStreamSynchronize(s));
     tail = ensure_staging(h, tail_bytes) == HIPBA_OK;
   }
   if (tail) {
-    // one round trip instead of three: everything the caller will read travels behind the last kernel
+    // one copy, one round trip: everything the caller will read sits at the start of the arena (build_resident)
     char* st = static_cast<char*>(h->staging);
-    HIPBA_HIP(hipMemcpyAsync(st, P.ws, sizeof(WinState) * P.n_windows, hipMemcpyDeviceToHost, s));
-    R->tail_ws = reinterpret_cast<const WinState*>(st);
-    size_t at = ws_bytes;
+    const char* base = static_cast<const char*>(R->arena);
+    HIPBA_HIP(hipMemcpyAsync(st, R->arena, tail_bytes, hipMemcpyDeviceToHost, s));
+    R->tail_ws = reinterpret_cast<const WinState*>(st + (reinterpret_cast<const char*>(P.ws) - base));
     for (int k = 0; k < 2; ++k) {
-      if (P.n_poses) HIPBA_HIP(hipMemcpyAsync(st + at, P.poses[k], sizeof(double) * 7 * P.n_poses, hipMemcpyDeviceToHost, s));
-      R->tail_poses[k] = reinterpret_cast<const double*>(st + at); at += pose_bytes;
-      if (P.n_pm_points) HIPBA_HIP(hipMemcpyAsync(st + at, P.points[k], sizeof(double) * 3 * P.n_pm_points, hipMemcpyDeviceToHost, s));
-      R->tail_points[k] = reinterpret_cast<const double*>(st + at); at += point_bytes;
+      R->tail_poses[k] = reinterpret_cast<const double*>(st + (reinterpret_cast<const char*>(P.poses[k]) - base));
+      R->tail_points[k] = reinterpret_cast<const double*>(st + (reinterpret_cast<const char*>(P.points[k]) - base));
     }
     HIPBA_HIP(hipStreamSynchronize(s));
-    memcpy(ws.data(), st, sizeof(WinState) * P.n_windows);
+    memcpy(ws.data(), R->tail_ws, sizeof(WinState) * P.n_windows);
     R->tail_valid = true;
-    R->d2h_bytes = (long long)sizeof(WinState) * P.n_windows + 2 * 8ll * (7ll * P.n_poses + 3ll * P.n_pm_points);
+    R->d2h_bytes = (long long)tail_bytes;
   } else {
     HIPBA_HIP(hipStreamSynchronize(s));
     HIPBA_HIP(hipMemcpy(ws.data(), P.ws, sizeof(WinState) * P.n_windows, hipMemcpyDeviceToHost));
