@@ -1284,6 +1284,13 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
   // development switch: HIPBA_SPLIT_LINEARIZE=1 keeps the camera blocks and the elimination in two launches (A/B timing)
   static const bool split_linearize = getenv("HIPBA_SPLIT_LINEARIZE") != nullptr;
   int iterations_run = 0;
+  // (a window with a few thousand observations keeps the GPU busy for longer than the host needs to see a count
+  // and queue a pass: one pass of lag is enough there and costs one idle pass at the end instead of two)
+  const int lag = (small && !sharded && P.n_windows <= 8) ? (P.n_act_obs >= 8000 ? 1 : 2) : 0;
+  // One small window: no event behind every pass (a packet of its own on the stream, and a wait in the runtime on
+  // this side); the host reads the word the control kernel stores into the pinned ring, tagged with the pass number.
+  const bool spin_poll = lag > 0 && P.n_windows == 1 && !timing;
+  if (spin_poll) for (int i = 0; i < 4; ++i) h->h_count[i] = 0;  // (nothing of an earlier solve is in flight: each ends in a synchronize)
   for (int iter = 1; iter <= std::max(lm.max_num_iterations, 0); ++iter) {
     PHASE(0);
     // S is zeroed first so that, unsharded, the camera-block launch can initialise the reduced system too
@@ -1358,12 +1365,13 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
     if (!cost_in_backsub) HIPBA_HIP(launch_cost(P, lm, 0, n_act_blk, 1, 0, true, s));
     PHASE(3);
     if (sharded) {
-      HIPBA_HIP(launch_window_control(P, lm, kReduce, nullptr, 0, s));
+      HIPBA_HIP(launch_window_control(P, lm, kReduce, nullptr, 0, 0, s));
       AR(P.wsum, 5, HIPBA_REDUCE_SUM);
-      HIPBA_HIP(launch_window_control(P, lm, kDecide, nullptr, 0, s));
+      HIPBA_HIP(launch_window_control(P, lm, kDecide, nullptr, 0, 0, s));
     } else {
       // a single window reports "still active" itself; batches are counted by k_count_active below
-      HIPBA_HIP(launch_window_control(P, lm, kFused, P.n_windows == 1 ? h->h_count + (iter & 3) : nullptr, control_zeroes_S ? 1 : 0, s));
+      HIPBA_HIP(launch_window_control(P, lm, kFused, P.n_windows == 1 ? h->h_count + (iter & 3) : nullptr, control_zeroes_S ? 1 : 0,
+                                      spin_poll ? iter << 1 : 0, s));
     }
     iterations_run = iter;
     // "windows still active" travels to the host through a ring of pinned words.  Small windows: the host looks
@@ -1374,15 +1382,31 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
     // (the kernels store the word straight into the pinned ring, which the device reaches at the same address: no
     // copy is queued behind them)
     if (sharded || P.n_windows != 1) HIPBA_HIP(launch_count_active(P, h->h_count + slot, s));
-    HIPBA_HIP(hipEventRecord(h->poll_ev[slot], s));
-    // (a window with a few thousand observations keeps the GPU busy for longer than the host needs to see a count
-    // and queue a pass: one pass of lag is enough there and costs one idle pass at the end instead of two)
-    const int lag = (small && !sharded && P.n_windows <= 8) ? (P.n_act_obs >= 8000 ? 1 : 2) : 0;
+    if (!spin_poll) HIPBA_HIP(hipEventRecord(h->poll_ev[slot], s));
     if (iter - lag >= 1) {
       const int seen = (iter - lag) & 3;
-      HIPBA_HIP(hipEventSynchronize(h->poll_ev[seen]));
-      if (timing) { const int rc = collect(iter - lag); if (rc) return rc; }
-      if (h->h_count[seen] == 0) break;
+      if (spin_poll) {
+        // the control kernel of pass iter - lag stores (pass << 1) | active straight into the ring: wait for that word
+        volatile int* word = h->h_count + seen;
+        const int want = iter - lag;
+        double deadline = 0.0;
+        for (long long spins = 0; (*word >> 1) != want; ++spins) {
+          if ((spins & 0xfff) == 0xfff) {
+            const double now = now_s();
+            if (deadline == 0.0) deadline = now + 10.0;
+            else if (now > deadline) {
+              // ten seconds for a pass of a small window: something is wrong on the device; let the runtime say what
+              HIPBA_HIP(hipStreamSynchronize(s));
+              if ((*word >> 1) != want) return fail(HIPBA_ERR_INTERNAL, "pass %d of the solve never reported back", want);
+            }
+          }
+        }
+        if ((*word & 1) == 0) break;
+      } else {
+        HIPBA_HIP(hipEventSynchronize(h->poll_ev[seen]));
+        if (timing) { const int rc = collect(iter - lag); if (rc) return rc; }
+        if (h->h_count[seen] == 0) break;
+      }
     }
   }
 #undef AR

@@ -29,7 +29,8 @@ bool backsub_can_carry_cost(const DevP& P);
 hipError_t launch_backsub(const DevP& P, const LmParams& lm, bool with_cost, hipStream_t s);
 hipError_t launch_pose_update(const DevP& P, hipStream_t s);
 hipError_t launch_window_init(const DevP& P, const LmParams& lm, int mode, hipStream_t s);
-hipError_t launch_window_control(const DevP& P, const LmParams& lm, int mode, int* count_out, int zero_S, hipStream_t s);
+hipError_t launch_window_control(const DevP& P, const LmParams& lm, int mode, int* count_out, int zero_S, int count_tag,
+                                 hipStream_t s);
 hipError_t launch_count_active(const DevP& P, int* out, hipStream_t s);
 hipError_t launch_residual_jacobian(const CameraK& K, const LmParams& lm, int apply_loss, long long n_obs,
                                     int n_poses, int n_points, const double* poses, const double* points, const int* obs_pose,

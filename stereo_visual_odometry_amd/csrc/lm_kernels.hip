@@ -1640,9 +1640,15 @@ __device__ __forceinline__ void window_control_body(const DevP& P, const LmParam
 // launch of k_count_active
 // zero_S: a window that goes on to another iteration has its packed reduced matrix zeroed here, so the host does
 // not queue a memset (a launch of its own on the iteration's critical path) before every pass
-__global__ __launch_bounds__(kWideBlock) void k_window_control(DevP P, LmParams lm, int mode, int* count_out, int zero_S) {
+// count_tag: OR-ed into that word (the pass number shifted left by one when the host polls the word itself instead of
+// an event behind this launch: it then needs to tell this pass's word from an older one); the store is pushed out to
+// the host at once
+__global__ __launch_bounds__(kWideBlock) void k_window_control(DevP P, LmParams lm, int mode, int* count_out, int zero_S,
+                                                             int count_tag) {
   window_control_body(P, lm, mode);
-  if (count_out && threadIdx.x == 0) *count_out = P.ws[blockIdx.x].active ? 1 : 0;
+  if (count_out && threadIdx.x == 0) {
+    __hip_atomic_store(count_out, count_tag | (P.ws[blockIdx.x].active ? 1 : 0), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   if (!zero_S) return;
   __syncthreads();  // the decision thread 0 has just written
   const WinState* st = P.ws + blockIdx.x;
@@ -2459,8 +2465,9 @@ hipError_t launch_window_init(const DevP& P, const LmParams& lm, int mode, hipSt
   return hipGetLastError();
 }
 
-hipError_t launch_window_control(const DevP& P, const LmParams& lm, int mode, int* count_out, int zero_S, hipStream_t s) {
-  hipLaunchKernelGGL(k_window_control, dim3(P.n_windows), dim3(window_threads(P)), 0, s, P, lm, mode, count_out, zero_S);
+hipError_t launch_window_control(const DevP& P, const LmParams& lm, int mode, int* count_out, int zero_S, int count_tag,
+                                 hipStream_t s) {
+  hipLaunchKernelGGL(k_window_control, dim3(P.n_windows), dim3(window_threads(P)), 0, s, P, lm, mode, count_out, zero_S, count_tag);
   return hipGetLastError();
 }
 
