@@ -1236,22 +1236,31 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
   P.dense_S = direct ? R->big.A : nullptr;
   P.dense_ld = direct ? R->big.ld : 0;
 
+  // small windows solved here alone: iteration 0 in fewer launches (below), S zeroed by the kernels (in the loop)
+  const bool short_start = small && !sharded && !direct && P.n_long == 0 && P.n_act_poses > 0 && o.report_time_breakdown == 0;
   // iteration 0: cost at the starting point, fixed cost, Jacobi scaling
-  HIPBA_HIP(launch_cost(P, lm, 0, n_act_blk, 0, 1, false, s));
-  HIPBA_HIP(launch_cost(P, lm, n_act_blk, P.n_blk_cc, 0, 1, false, s));
+  HIPBA_HIP(launch_cost(P, lm, 0, n_act_blk + (short_start ? P.n_blk_cc : 0), 0, 1, false, s));
+  if (!short_start) HIPBA_HIP(launch_cost(P, lm, n_act_blk, P.n_blk_cc, 0, 1, false, s));
   if (sharded) {
-    HIPBA_HIP(launch_window_init(P, lm, kReduce, s));
+    HIPBA_HIP(launch_window_init(P, lm, kReduce, 0, s));
     // fixed cost belongs to the rank that owns the pose-only blocks; every rank evaluates the same CC
     // list only if it was given one, so the sum is what the caller sharded
     AR(P.wsum, 3, HIPBA_REDUCE_SUM);
-    HIPBA_HIP(launch_window_init(P, lm, kDecide, s));
+    HIPBA_HIP(launch_window_init(P, lm, kDecide, 0, s));
   } else {
-    HIPBA_HIP(launch_window_init(P, lm, kFused, s));
+    HIPBA_HIP(launch_window_init(P, lm, kFused, short_start ? 1 : 0, s));
   }
-  HIPBA_HIP(launch_camera_blocks(P, lm, 0, 0, s));
-  if (sharded && P.n_act_poses) { AR(P.U, 36 * (size_t)P.n_act_poses, HIPBA_REDUCE_SUM); AR(P.gc, 6 * (size_t)P.n_act_poses, HIPBA_REDUCE_SUM); }
-  HIPBA_HIP(launch_make_scale_c(P, lm.jacobi_scaling, s));
-  HIPBA_HIP(launch_point_colnorm(P, lm, s));
+  if (short_start) {
+    // two launches: unscaled camera blocks beside the landmarks' column norms, then the pose scaling with the
+    // reduced system's initialisation for the first pass (S and b were zeroed by k_window_init)
+    HIPBA_HIP(launch_first_blocks(P, lm, s));
+    HIPBA_HIP(launch_scale_init_reduced(P, lm, lm.jacobi_scaling, s));
+  } else {
+    HIPBA_HIP(launch_camera_blocks(P, lm, 0, 0, s));
+    if (sharded && P.n_act_poses) { AR(P.U, 36 * (size_t)P.n_act_poses, HIPBA_REDUCE_SUM); AR(P.gc, 6 * (size_t)P.n_act_poses, HIPBA_REDUCE_SUM); }
+    HIPBA_HIP(launch_make_scale_c(P, lm.jacobi_scaling, s));
+    HIPBA_HIP(launch_point_colnorm(P, lm, s));
+  }
 
   // optional per-phase device times (FullReport's evaluation / linear-solver split)
   const bool timing = o.report_time_breakdown != 0;
@@ -1296,7 +1305,7 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
     // S is zeroed first so that, unsharded, the camera-block launch can initialise the reduced system too
     if (direct) {
       if (!R->S_fully_written || sharded) HIPBA_HIP(big_zero_lower(P, R->big, env_ready, s));
-    } else if (R->S_doubles && !(R->S_fully_written && !sharded) && !(control_zeroes_S && iter > 1)) {
+    } else if (R->S_doubles && !(R->S_fully_written && !sharded) && !(control_zeroes_S && iter > 1) && !short_start) {
       HIPBA_HIP(hipMemsetAsync(P.S, 0, sizeof(double) * (size_t)R->S_doubles, s));
     }
     const bool fuse_init = iter > 1 && !sharded;
@@ -1310,7 +1319,7 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
       if (sharded && P.n_act_poses) { AR(P.U, 36 * (size_t)P.n_act_poses, HIPBA_REDUCE_SUM); AR(P.gc, 6 * (size_t)P.n_act_poses, HIPBA_REDUCE_SUM); }
     }
     PHASE(1);
-    if (!fuse_init) HIPBA_HIP(launch_init_reduced(P, lm, owner, s));
+    if (!fuse_init && !(short_start && iter == 1)) HIPBA_HIP(launch_init_reduced(P, lm, owner, s));
     if (!one_launch) HIPBA_HIP(launch_point_schur(P, lm, small_ncam, schur_parts, s));
     if (sharded) {
       const bool piped = direct && feed.n_chunks > 0 && solver == HIPBA_LINEAR_DENSE_CHOLESKY;
@@ -2183,7 +2192,7 @@ int hipba_time_kernel(hipba_handle h, hipba_device_problem dp, const hipba_optio
     auto prepare = [&]() -> int {
       HIPBA_HIP(launch_cost(P, lm, 0, n_act_blk, 0, 1, false, s));
       HIPBA_HIP(launch_cost(P, lm, n_act_blk, P.n_blk_cc, 0, 1, false, s));
-      HIPBA_HIP(launch_window_init(P, lm, kFused, s));
+      HIPBA_HIP(launch_window_init(P, lm, kFused, 0, s));
       HIPBA_HIP(launch_camera_blocks(P, lm, 0, 0, s));
       HIPBA_HIP(launch_make_scale_c(P, lm.jacobi_scaling, s));
       HIPBA_HIP(launch_point_colnorm(P, lm, s));

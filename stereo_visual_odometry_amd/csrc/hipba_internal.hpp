@@ -28,7 +28,9 @@ hipError_t launch_window_gradient(const DevP& P, const LmParams& lm, int mode, h
 bool backsub_can_carry_cost(const DevP& P);
 hipError_t launch_backsub(const DevP& P, const LmParams& lm, bool with_cost, hipStream_t s);
 hipError_t launch_pose_update(const DevP& P, hipStream_t s);
-hipError_t launch_window_init(const DevP& P, const LmParams& lm, int mode, hipStream_t s);
+hipError_t launch_window_init(const DevP& P, const LmParams& lm, int mode, int zero_S, hipStream_t s);
+hipError_t launch_first_blocks(const DevP& P, const LmParams& lm, hipStream_t s);
+hipError_t launch_scale_init_reduced(const DevP& P, const LmParams& lm, int jacobi, hipStream_t s);
 hipError_t launch_window_control(const DevP& P, const LmParams& lm, int mode, int* count_out, int zero_S, int count_tag,
                                  hipStream_t s);
 hipError_t launch_count_active(const DevP& P, int* out, hipStream_t s);

@@ -329,9 +329,7 @@ __global__ __launch_bounds__(kBlock) void k_camera_blocks(DevP P, LmParams lm, i
 
 // Jacobi scaling of the pose columns, computed once at iteration 0 from the unscaled blocks
 // (Ceres: scale = 1 / (1 + sqrt(squared column norm))), then folded into U and g.
-__global__ void k_make_scale_c(DevP P, int jacobi) {
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= P.n_act_poses) return;
+__device__ __forceinline__ void make_scale_c_pose(const DevP& P, int g, int jacobi) {
   double* U = P.U + 36ll * g;
   double s[6];
 #pragma unroll
@@ -347,10 +345,24 @@ __global__ void k_make_scale_c(DevP P, int jacobi) {
   }
 }
 
+__global__ void k_make_scale_c(DevP P, int jacobi) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= P.n_act_poses) return;
+  make_scale_c_pose(P, g, jacobi);
+}
+
+// the same, and the thread goes on to initialise the reduced system for the first pass (k_init_reduced's work: it
+// needs this pose's scaled block only); S and b must hold zeros
+__global__ void k_scale_init_reduced(DevP P, LmParams lm, int jacobi) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= P.n_act_poses) return;
+  make_scale_c_pose(P, g, jacobi);
+  init_reduced_pose(P, lm, g, 1);
+}
+
 // Jacobi scaling of the landmark columns (iteration 0): unscaled squared column norms per landmark.
-__global__ __launch_bounds__(kBlock) void k_point_colnorm(DevP P, LmParams lm) {
-  __shared__ double sh[kBlock * 3];
-  const BlockDesc d = P.blocks[blockIdx.x];
+__device__ __forceinline__ void point_colnorm_body(const DevP& P, const LmParams& lm, int blk, double* sh) {
+  const BlockDesc d = P.blocks[blk];
   const WinState* st = P.ws + d.window;
   if (!st->active || d.pad) return;  // (a piece of a long landmark: k_long_point's)
   const int sel = st->sel;
@@ -382,6 +394,19 @@ __global__ __launch_bounds__(kBlock) void k_point_colnorm(DevP P, LmParams lm) {
       for (int i = 0; i < 3; ++i) P.scale_p[3ll * pp + i] = lm.jacobi_scaling ? 1.0 / (1.0 + sqrt(n[i])) : 1.0;
     }
   }
+}
+
+__global__ __launch_bounds__(kBlock) void k_point_colnorm(DevP P, LmParams lm) {
+  __shared__ double sh[kBlock * 3];
+  point_colnorm_body(P, lm, blockIdx.x, sh);
+}
+
+// iteration 0 of small windows: the unscaled camera blocks (the first P.n_act_poses workgroups) and the landmarks'
+// column norms (the others) have nothing to do with each other: one launch
+__global__ __launch_bounds__(kBlock) void k_first_blocks(DevP P, LmParams lm) {
+  __shared__ double sh[kBlock * 3];
+  if ((int)blockIdx.x < P.n_act_poses) camera_blocks_body(P, lm, blockIdx.x, 0, 0, sh);
+  else point_colnorm_body(P, lm, (int)blockIdx.x - P.n_act_poses, sh);
 }
 
 
@@ -1408,11 +1433,20 @@ __device__ __forceinline__ void log_iteration(const DevP& P, const WinDesc& wd, 
 constexpr int kWsum = 8;  // doubles of P.wsum per window
 
 // iteration 0: initial cost, fixed cost, state reset
-__global__ __launch_bounds__(kBlock) void k_window_init(DevP P, LmParams lm, int mode) {
+// zero_S: the window's packed reduced matrix and right-hand side are zeroed for the first pass (small windows: no
+// memset queued by the host)
+__global__ __launch_bounds__(kBlock) void k_window_init(DevP P, LmParams lm, int mode, int zero_S) {
   __shared__ double red[3 * 4];
   const int w = blockIdx.x;
   const WinDesc wd = P.wd[w];
   WinState* st = P.ws + w;
+  if (zero_S) {
+    double2* Sw = reinterpret_cast<double2*>(P.S + wd.S_off);
+    const long long n2 = 18ll * ((long long)wd.ncam * (wd.ncam + 1) / 2);
+    for (long long i = threadIdx.x; i < n2; i += kBlock) Sw[i] = make_double2(0.0, 0.0);
+    double2* bw = reinterpret_cast<double2*>(P.b + 6ll * wd.cam_base);
+    for (int i = threadIdx.x; i < 3 * wd.ncam; i += kBlock) bw[i] = make_double2(0.0, 0.0);
+  }
   double acc[3] = {0.0, 0.0, 0.0};
   if (mode != kDecide) {
     for (int b = wd.pm_blk_begin + threadIdx.x; b < wd.pm_blk_end; b += kBlock) {
@@ -2354,6 +2388,19 @@ hipError_t launch_make_scale_c(const DevP& P, int jacobi, hipStream_t s) {
   return hipGetLastError();
 }
 
+// iteration 0 of small windows in two launches instead of four (see k_first_blocks, k_scale_init_reduced)
+hipError_t launch_first_blocks(const DevP& P, const LmParams& lm, hipStream_t s) {
+  const unsigned grid = (unsigned)std::max(P.n_act_poses, 0) + (unsigned)std::max(P.n_blk_pm, 0);
+  if (grid == 0 || P.n_long > 0) return grid == 0 ? hipSuccess : hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_first_blocks, dim3(grid), dim3(kBlock), 0, s, P, lm);
+  return hipGetLastError();
+}
+hipError_t launch_scale_init_reduced(const DevP& P, const LmParams& lm, int jacobi, hipStream_t s) {
+  if (P.n_act_poses <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_scale_init_reduced, dim3((P.n_act_poses + 255) / 256), dim3(256), 0, s, P, lm, jacobi);
+  return hipGetLastError();
+}
+
 hipError_t launch_point_colnorm(const DevP& P, const LmParams& lm, hipStream_t s) {
   if (P.n_blk_pm <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_point_colnorm, dim3(P.n_blk_pm), dim3(kBlock), 0, s, P, lm);
@@ -2460,8 +2507,8 @@ hipError_t launch_pose_update(const DevP& P, hipStream_t s) {
   return hipGetLastError();
 }
 
-hipError_t launch_window_init(const DevP& P, const LmParams& lm, int mode, hipStream_t s) {
-  hipLaunchKernelGGL(k_window_init, dim3(P.n_windows), dim3(kBlock), 0, s, P, lm, mode);
+hipError_t launch_window_init(const DevP& P, const LmParams& lm, int mode, int zero_S, hipStream_t s) {
+  hipLaunchKernelGGL(k_window_init, dim3(P.n_windows), dim3(kBlock), 0, s, P, lm, mode, zero_S);
   return hipGetLastError();
 }
 
