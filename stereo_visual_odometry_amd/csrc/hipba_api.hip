@@ -23,6 +23,7 @@
 #include <string>
 #include <system_error>
 #include <thread>
+#include <limits>
 #include <vector>
 
 #include "camera_order.hpp"
@@ -514,6 +515,15 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   std::vector<int> obs_pose(std::max<long long>(n_all, 1)), obs_dp(std::max<long long>(n_all, 1));
   std::vector<double> obs_uv(std::max<long long>(2 * n_all, 2));
   std::vector<int> vc_window_count(nw, 0), cc_window_count(nw, 0);
+  // Per variable landmark, gathered while its observations are dropped into place: how many of them are by variable
+  // poses, and -- where the slots are final already (every case but the one large window, whose poses are reordered
+  // below) -- whether its segment arrives sorted by (slot, pose) and free of repeats.  A caller that lists its
+  // observations frame by frame (the reference does: optimizer.cpp:37-51) hands over sorted segments, and the two
+  // passes over the observations that sort the segments and look for repeats are then skipped.
+  const bool dense_path = nw == 1 && 6 * max_ncam > kSmallMaxN;
+  std::vector<int> nvar(std::max(n_pm_points, 1), 0);
+  std::vector<long long> last_key(dense_path ? 0 : std::max(n_pm_points, 1), std::numeric_limits<long long>::min());
+  bool seg_unsorted = false, seg_repeat = false;
   {
     std::vector<long long> cur(pp_start.begin(), pp_start.end() - 1);
     long long vc_cur = n_pm_obs, cc_cur = n_act_obs;
@@ -523,7 +533,17 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
         const long long gp = pt_base[w] + p.obs_point[k];
         const int c = R->meta[w].pose_base + p.obs_pose[k];
         long long dst;
-        if (!pt_c[gp]) dst = cur[dp_of[gp]]++;
+        if (!pt_c[gp]) {
+          const int d = dp_of[gp], g = pose_gslot[c];
+          dst = cur[d]++;
+          nvar[d] += g >= 0;
+          if (!dense_path) {
+            const long long key = ((long long)g << 32) + c;
+            if (key < last_key[d]) seg_unsorted = true;
+            else if (key == last_key[d] && g >= 0) seg_repeat = true;
+            last_key[d] = key;
+          }
+        }
         else if (!pose_c[c]) { dst = vc_cur++; vc_window_count[w]++; }
         else { dst = cc_cur++; cc_window_count[w]++; }
         obs_pose[dst] = c;
@@ -537,7 +557,7 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
 
   SETUP_MARK("observations");
   // ---- order of the poses in the reduced system (one large window: the dense factorisation's envelope) --------
-  const bool dense_path = nw == 1 && 6 * max_ncam > kSmallMaxN;
+  const bool segments_known_clean = !dense_path && !seg_unsorted && !seg_repeat;  // sorted by slot, no pose twice
   if (dense_path) {
     const int ncam = n_slots;
     const int n_tiles = (6 * ncam + kCholNB - 1) / kCholNB;
@@ -586,7 +606,7 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   }
   // sort each landmark's segment by slot (constant poses, slot -1, first; ties by pose index): the pair lists want
   // slot_i <= slot_j for i < j, and repeated observations by one pose next to each other
-  for (int pp = 0; pp < n_pm_points; ++pp) {
+  for (int pp = 0; pp < n_pm_points && (dense_path || seg_unsorted); ++pp) {
     const long long s0 = pp_start[pp], s1 = pp_start[pp + 1];
     for (long long i = s0 + 1; i < s1; ++i) {
       const int cp = obs_pose[i];
@@ -641,20 +661,18 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
         }
         L.n_blk = (int)blocks.size() - L.blk_begin;
         longs.push_back(L);
-        long long v = 0;
-        for (long long o = pp_start[pp]; o < pp_start[pp + 1]; ++o) v += pose_gslot[obs_pose[o]] >= 0;
+        const long long v = nvar[pp];
         pairs_all += v * (v + 1) / 2;
         ++pp;
         continue;
       }
       while (pp < wd[w].pp_end && n + (int)(pp_start[pp + 1] - pp_start[pp]) <= kBlock) {
         const int s1 = n + (int)(pp_start[pp + 1] - pp_start[pp]);
-        int v = 0;
-        for (int i = n; i < s1; ++i) v += pose_gslot[obs_pose[d.obs_begin + i]] >= 0;
+        const int v = nvar[pp];
         np += v * (v + 1) / 2;
         // a pose that observes the landmark m times (m residual blocks, legal in ceres::Problem) adds m (m - 1) / 2
         // mirrored pairs: see generate_pairs.  The segment is sorted by pose, so repeats are adjacent.
-        for (int i = n, run = 1; i < s1; ++i) {
+        for (int i = n, run = 1; i < s1 && !segments_known_clean; ++i) {
           const bool same = i + 1 < s1 && obs_pose[d.obs_begin + i + 1] == obs_pose[d.obs_begin + i];
           if (same) { ++run; continue; }
           if (pose_gslot[obs_pose[d.obs_begin + i]] >= 0) { np += run * (run - 1) / 2; has_dup |= run > 1; }

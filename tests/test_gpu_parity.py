@@ -718,6 +718,29 @@ def test_window_sizes_across_the_accumulation_modes(solver, oracle, n_frames):
     _check_against_oracle(oracle, prob, g, s)
 
 
+@pytest.mark.parametrize("order", ["by_frame", "shuffled", "shuffled_with_repeats"])
+def test_observation_order_of_the_caller(solver, oracle, order):
+    """The host analysis skips its sorting pass when every landmark's observations arrive in slot order (a caller that
+    walks its frames one after the other, as optimizer.cpp:37-51 does) and must not when they do not: the same window
+    listed frame by frame, in random order, and in random order with some (pose, landmark) pairs observed twice."""
+    prob, _, _ = scenes.small_window(4400, n_frames=12, n_points=500)
+    rng = np.random.default_rng(11)
+    n = prob.obs_pose.shape[0]
+    if order == "by_frame":
+        perm = np.lexsort((prob.obs_point, prob.obs_pose))
+    else:
+        perm = rng.permutation(n)
+    op, oq, uv = prob.obs_pose[perm], prob.obs_point[perm], prob.obs_uv[perm]
+    if order == "shuffled_with_repeats":
+        pick = rng.choice(n, size=n // 20, replace=False)
+        op, oq = np.concatenate([op, op[pick]]), np.concatenate([oq, oq[pick]])
+        uv = np.concatenate([uv, uv[pick] + rng.normal(0, 0.3, (len(pick), 2))])
+    d = hipba.Problem(prob.poses, prob.points, op, oq, uv, prob.K, prob.camera_model, prob.pose_const, prob.point_const)
+    g = d.copy()
+    s = solver.solve(g, hipba.default_options(max_num_iterations=100))
+    _check_against_oracle(oracle, d, g, s, max_iter=100)
+
+
 def test_mixed_batch_of_window_sizes_with_huber_loss(solver, oracle):
     wins = [scenes.small_window(4100 + i, n_frames=nf, n_points=300)[0] for i, nf in enumerate([2, 5, 9, 14, 20, 26, 32])]
     batch = [w.copy() for w in wins]
