@@ -93,22 +93,6 @@ class HostWorkers {
     job_ = nullptr;
     return !failed_;
   }
-  // f(1) on a worker while the caller goes on; f must stay alive until wait() has returned.  No other job in between.
-  void start(const std::function<void(int)>& f) {
-    failed_ = false;
-    if (threads_.empty()) threads_.emplace_back([this] { loop(1); });
-    {
-      std::lock_guard<std::mutex> lk(m_);
-      job_ = &f; parts_ = 2; pending_ = 1; ++generation_;
-    }
-    go_.notify_all();
-  }
-  bool wait() {
-    std::unique_lock<std::mutex> lk(m_);
-    done_.wait(lk, [this] { return pending_ == 0; });
-    job_ = nullptr;
-    return !failed_;
-  }
 
  private:
   void call(const std::function<void(int)>& f, int i) {
@@ -465,7 +449,8 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   // ---- camera-major lists and the parameters in device order -----------------------------------------
   // Straight from the caller's arrays (every observation by a variable pose, in the caller's order), so they depend
   // on nothing below but the slots: for windows whose slots are final here (not the one large window whose poses are
-  // reordered further down) a worker of the handle builds them while this thread sorts the observations by landmark.
+  // reordered further down) a worker of the handle builds them beside the threads that sort the observations by
+  // landmark.
   std::vector<long long> cm_start(n_slots + 1, 0);
   std::vector<int> cm_dp;
   std::vector<double> cm_uv;
@@ -494,17 +479,7 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
       }
     }
   };
-  const std::function<void(int)> side_lists_job = [&](int) { build_side_lists(); };
-  bool side_lists_async = false;
-  // (joins the worker on every way out of this function: it works on this frame's vectors)
-  struct JoinWorker {
-    HostWorkers& w; bool& active;
-    ~JoinWorker() { if (active) (void)w.wait(); }
-  } join_worker{h->workers, side_lists_async};
-  if (!(nw == 1 && 6 * max_ncam > kSmallMaxN) && n_slots > 0) {
-    h->workers.start(side_lists_job);
-    side_lists_async = true;
-  }
+  bool side_lists_done = false;
   // ---- observations: PM | VC | CC --------------------------------------------------------------
   std::vector<long long> pp_start(n_pm_points + 1, 0);
   for (long long gp = 0; gp < NPT; ++gp)
@@ -525,34 +500,63 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   std::vector<long long> last_key(dense_path ? 0 : std::max(n_pm_points, 1), std::numeric_limits<long long>::min());
   bool seg_unsorted = false, seg_repeat = false;
   {
+    // The landmarks are cut into ranges, one per thread: every thread reads all observations and places those of its
+    // landmarks (what it writes -- cursors, counts, the segments themselves -- is its own); thread 0 also places the
+    // observations of constant landmarks.  Beside them one more thread builds the camera-major lists, which need
+    // nothing from here.  Small inputs: one thread does it all, lists included.
     std::vector<long long> cur(pp_start.begin(), pp_start.end() - 1);
-    long long vc_cur = n_pm_obs, cc_cur = n_act_obs;
-    for (int w = 0; w < nw; ++w) {
-      const hipba_problem& p = probs[w];
-      for (long long k = 0; k < p.n_obs; ++k) {
-        const long long gp = pt_base[w] + p.obs_point[k];
-        const int c = R->meta[w].pose_base + p.obs_pose[k];
-        long long dst;
-        if (!pt_c[gp]) {
-          const int d = dp_of[gp], g = pose_gslot[c];
-          dst = cur[d]++;
-          nvar[d] += g >= 0;
-          if (!dense_path) {
-            const long long key = ((long long)g << 32) + c;
-            if (key < last_key[d]) seg_unsorted = true;
-            else if (key == last_key[d] && g >= 0) seg_repeat = true;
-            last_key[d] = key;
+    const int n_parts = n_all >= 12000 ? 3 : 1;
+    bool part_unsorted[4] = {false, false, false, false}, part_repeat[4] = {false, false, false, false};
+    auto place = [&](int part) {
+      const int d_lo = (int)((long long)n_pm_points * part / n_parts), d_hi = (int)((long long)n_pm_points * (part + 1) / n_parts);
+      long long vc_cur = n_pm_obs, cc_cur = n_act_obs;
+      bool unsorted = false, repeat = false;
+      for (int w = 0; w < nw; ++w) {
+        const hipba_problem& p = probs[w];
+        const int pose_base = R->meta[w].pose_base;
+        for (long long k = 0; k < p.n_obs; ++k) {
+          const long long gp = pt_base[w] + p.obs_point[k];
+          long long dst;
+          int c;
+          if (!pt_c[gp]) {
+            const int d = dp_of[gp];
+            if (d < d_lo || d >= d_hi) continue;
+            c = pose_base + p.obs_pose[k];
+            const int g = pose_gslot[c];
+            dst = cur[d]++;
+            nvar[d] += g >= 0;
+            if (!dense_path) {
+              const long long key = ((long long)g << 32) + c;
+              if (key < last_key[d]) unsorted = true;
+              else if (key == last_key[d] && g >= 0) repeat = true;
+              last_key[d] = key;
+            }
+          } else {
+            if (part != 0) continue;
+            c = pose_base + p.obs_pose[k];
+            if (!pose_c[c]) { dst = vc_cur++; vc_window_count[w]++; }
+            else { dst = cc_cur++; cc_window_count[w]++; }
           }
+          obs_pose[dst] = c;
+          obs_dp[dst] = dp_of[gp];
+          obs_uv[2 * dst] = p.obs_uv[2 * k];
+          obs_uv[2 * dst + 1] = p.obs_uv[2 * k + 1];
         }
-        else if (!pose_c[c]) { dst = vc_cur++; vc_window_count[w]++; }
-        else { dst = cc_cur++; cc_window_count[w]++; }
-        obs_pose[dst] = c;
-        obs_dp[dst] = dp_of[gp];
-        obs_uv[2 * dst] = p.obs_uv[2 * k];
-        obs_uv[2 * dst + 1] = p.obs_uv[2 * k + 1];
       }
-      R->meta[w].n_act_obs = 0;
+      part_unsorted[part] = unsorted; part_repeat[part] = repeat;
+    };
+    const bool lists_here = !dense_path && n_slots > 0;  // (the large window's slots are not final yet)
+    if (n_parts == 1) {
+      place(0);
+      if (lists_here) { build_side_lists(); side_lists_done = true; }
+    } else {
+      const int n_jobs = n_parts + (lists_here ? 1 : 0);
+      if (!h->workers.run(n_jobs, [&](int i) { if (i < n_parts) place(i); else build_side_lists(); }))
+        return fail(HIPBA_ERR_OUT_OF_MEMORY, "host analysis of the observations ran out of memory");
+      side_lists_done = lists_here;
     }
+    for (int i = 0; i < n_parts; ++i) { seg_unsorted |= part_unsorted[i]; seg_repeat |= part_repeat[i]; }
+    for (int w = 0; w < nw; ++w) R->meta[w].n_act_obs = 0;
   }
 
   SETUP_MARK("observations");
@@ -826,12 +830,7 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
 
   SETUP_MARK("gathered lists");
   // the camera-major lists: built meanwhile by a worker (small windows), or here now that the slots are final
-  if (side_lists_async) {
-    side_lists_async = false;
-    if (!h->workers.wait()) return fail(HIPBA_ERR_OUT_OF_MEMORY, "host analysis of the camera-major lists ran out of memory");
-  } else {
-    build_side_lists();
-  }
+  if (!side_lists_done) build_side_lists();
 
   // ---- atomic / LDS accumulation: each block's pair list grouped by destination block and cut into runs
   // of at most kRunMax pairs with one destination; a lane group sums a run in registers and adds it to
