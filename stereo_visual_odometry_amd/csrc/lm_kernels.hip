@@ -2027,58 +2027,50 @@ __global__ __launch_bounds__(kSolveThreads) void k_window_solve_tiles(DevP P, Lm
   if (!st->active) return;
   HIPBA_TICK(0);
   const WinDesc wd = P.wd[w];
+  const int nb = wd.ncam;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const double* Sg = P.S + wd.S_off;
+  // Packed upper 6x6 blocks (row-major inside a block) -> lower 16x16 tiles in LDS, walked in the order of the
+  // DESTINATION: half the workgroup per tile, a lane per word of it, so the LDS stores are linear and all a lane
+  // computes is where its word comes from: entry (r, c), r >= c, of S lies in block (c / 6, r / 6) -- at (c % 6, r % 6)
+  // of an off-diagonal block, at (r % 6, c % 6) of a diagonal one (whose entries on and below the diagonal are the
+  // ones used).  Rows n and beyond (all in the last tile row) are the identity.  Every word -- at most 39 per lane
+  // for 192 unknowns -- is requested HERE, before the gradient test, whose reductions and barriers run while they
+  // travel.  (Walked in the order of the source, with each word dropped at its place, this took 8 us after a 4 us
+  // test: 32 scattered stores per lane behind a data-dependent walk of the block rows.)
+  constexpr int kPre = (kSmallMaxN / TB) * (kSmallMaxN / TB + 1) / 4;  // tiles of the largest window / 2
+  const int n = 6 * nb, nt = (n + TB - 1) / TB, ntl = nt * (nt + 1) / 2;
+  const int half = t >> 8, ent = t & 255, ep = ent & 15, eq = ent >> 4;
+  double pre[kPre];
+  {
+    int ti = 0, tj = half;  // tile (ti, tj) of this half's first tile: linear index `half`
+    while (tj > ti) { tj -= ti + 1; ++ti; }
+#pragma unroll
+    for (int k = 0; k < kPre; ++k) {
+      double v = 0.0;
+      if (2 * k + half < ntl) {
+        const int r = TB * ti + ep, cc = TB * tj + eq;
+        if (r >= n) v = r == cc ? 1.0 : 0.0;
+        else if (r >= cc) {
+          const int bi = cc / 6, bj = r / 6;
+          const int blk = bi * nb - bi * (bi - 1) / 2 + (bj - bi);
+          v = Sg[36ll * blk + (bi == bj ? 6 * (r - 6 * bi) + (cc - 6 * bi) : 6 * (cc - 6 * bi) + (r - 6 * bj))];
+        }
+      }
+      pre[k] = v;
+      tj += 2;
+      while (tj > ti) { tj -= ti + 1; ++ti; }
+    }
+  }
   window_gradient_check(P, lm, wd, st, red, kFused);
   HIPBA_TICK(1);
   if (!st->active) return;
-  const int nb = wd.ncam;
   if (nb == 0) return;
-  const int n = 6 * nb, nt = (n + TB - 1) / TB, ntl = nt * (nt + 1) / 2;
   double* Lt = smem + 16;
   double* zb = Lt + (size_t)ntl * kTile;               // right-hand side, then z = L^-1 b, then y
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const double* Sg = P.S + wd.S_off;
-  // packed upper 6x6 blocks (row-major inside a block) -> lower tiles.  The padding rows (n and beyond, all in the
-  // last tile row) are zero with a unit diagonal; the packed words are read in order (coalesced) and each is dropped
-  // at its place: entry (a, c) of block (bi, bj), bi < bj, is S(6 bj + c, 6 bi + a); of a diagonal block the entries
-  // a >= c.  (What lies above the diagonal inside a diagonal tile is never written: nothing below ever reads it.)
-  {
-    const int pad0 = n - TB * (nt - 1);  // first padding row inside the last tile row
-    for (int e = t; e < nt * kTile; e += kSolveThreads) {
-      const int bj = e >> 8, in = e & 255, pr = in & 15, qc = in >> 4;
-      if (pr >= pad0) Lt[ltile(nt - 1, bj) + in] = (bj == nt - 1 && pr == qc) ? 1.0 : 0.0;
-    }
-  }
-  {
-    // 14 groups of 36 lanes: a lane keeps its entry (a, c) and its group walks every 14th block, so the block's row
-    // and column are advanced, not recomputed; eight blocks' loads are in flight per lane
-    constexpr int kGroups = kSolveThreads / 36;
-    const int grp = t / 36, in = t - 36 * grp, a = in / 6, c = in - 6 * a;
-    const int nblk = nb * (nb + 1) / 2;
-    int bi = 0, off = grp;  // block (bi, bi + off)
-    if (grp < kGroups) {
-      for (int blk0 = grp; blk0 < nblk; blk0 += 8 * kGroups) {
-        double v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int blk = blk0 + u * kGroups;
-          v[u] = blk < nblk ? Sg[36ll * blk + in] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int blk = blk0 + u * kGroups;
-          if (blk < nblk) {
-            while (off >= nb - bi) { off -= nb - bi; ++bi; }
-            const int bj = bi + off;
-            if (bi != bj || a >= c) {
-              const int r = bi == bj ? 6 * bi + a : 6 * bj + c, cc = bi == bj ? 6 * bi + c : 6 * bi + a;
-              Lt[ltile(r / TB, cc / TB) + (cc % TB) * TB + (r % TB)] = v[u];
-            }
-          }
-          off += kGroups;
-        }
-      }
-    }
-  }
+  for (int k = 0; k < kPre; ++k)
+    if (2 * k + half < ntl) Lt[(2 * k + half) * kTile + ent] = pre[k];
   for (int i = t; i < TB * nt; i += kSolveThreads) zb[i] = i < n ? P.b[6ll * wd.cam_base + i] : 0.0;
   if (t == 0) fail = 0;
   __syncthreads();
