@@ -52,7 +52,10 @@ def main():
     if which == "kitti":
         ms = dp.time_kernel(hipba.KERNEL_REDUCED_SOLVE, 5)
         lib.hipba_debug_ticks(buf, 8 * n)
-        t = np.frombuffer(buf, dtype=np.uint64).reshape(n, 8).astype(np.int64)[0]
+        tt = np.frombuffer(buf, dtype=np.uint64).reshape(n, 8).astype(np.int64)
+        print("factor loop, shader cycles: wave 0 panel %d, wait %d, diagonal tile %d, wait %d; wave 1 panel %d, wait %d, trailing %d, wait %d" % (
+            *tt[1][:4], *tt[2][:4]))
+        t = tt[0]
         print("reduced_solve %.1f us: gradient check %.2f, load %.2f, factor %.2f, back sweep %.2f us" % (
             1e3 * ms, *[(t[i + 1] - t[i]) * 10e-3 for i in range(4)]))
         print("factor phase: %d shader cycles in %.2f us -> %.0f MHz" % (t[6] - t[5], (t[3] - t[2]) * 10e-3,

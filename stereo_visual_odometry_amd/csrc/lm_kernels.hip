@@ -2078,6 +2078,12 @@ __global__ __launch_bounds__(kSolveThreads) void k_window_solve_tiles(DevP P, Lm
   HIPBA_CYCLES(5);
   if (wave == 0 && !tile_cholesky_inverse(Lt, nullptr, 0, lane) && lane == 0) fail = 1;
   __syncthreads();
+#ifdef HIPBA_PHASE_TIMING
+  long long tq[4] = {0, 0, 0, 0}, tprev = clock64();
+#define HIPBA_LAP(i) do { const long long now_ = clock64(); tq[i] += now_ - tprev; tprev = now_; } while (0)
+#else
+#define HIPBA_LAP(i)
+#endif
   for (int j = 0; j < nt; ++j) {
     if (fail) break;
     // panel below the diagonal tile: L(i,j) = A(i,j) L(j,j)^-T (the result replaces the tile)
@@ -2090,11 +2096,15 @@ __global__ __launch_bounds__(kSolveThreads) void k_window_solve_tiles(DevP P, Lm
         tile_store_t(T, acc, lane);
       }
     }
+    HIPBA_LAP(0);
     __syncthreads();
+    HIPBA_LAP(1);
     // trailing tiles: A(i2,j2) -= L(i2,j) L(j2,j)^T.  Wave 0 takes the next diagonal tile alone and factors it at
     // once (the longest single-wave job of a step) while the other waves share the remaining tiles.
     if (wave == 0) {
       if (j + 1 < nt) {
+        // (raised priority: the wave shares its SIMD with one of the updating waves, and this is the step's longest job)
+        __builtin_amdgcn_s_setprio(3);
         double* C = Lt + ltile(j + 1, j + 1);
         v4d acc = tile_load_t(C, lane);
         acc = mfma_tile<true>(Lt + ltile(j + 1, j), Lt + ltile(j + 1, j), acc, lane);
@@ -2103,21 +2113,59 @@ __global__ __launch_bounds__(kSolveThreads) void k_window_solve_tiles(DevP P, Lm
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (!tile_cholesky_inverse(C, nullptr, 0, lane) && lane == 0) fail = 1;
+        __builtin_amdgcn_s_setprio(0);
       }
     } else {
-      int e = 0;
-      for (int i2 = j + 2; i2 < nt; ++i2) {
-        for (int j2 = j + 1; j2 <= i2; ++j2, ++e) {
-          if (e % (kSolveThreads / 64 - 1) != wave - 1) continue;
-          double* C = Lt + ltile(i2, j2);
-          v4d acc = tile_load_t(C, lane);
-          acc = mfma_tile<true>(Lt + ltile(j2, j), Lt + ltile(i2, j), acc, lane);
-          tile_store_t(C, acc, lane);
+      // this wave's tiles of the trailing block: every seventh of the row-by-row list (row i2 holds j2 = j + 1 .. i2),
+      // walked directly -- scanning the whole list with a modulo test per tile cost as much as the products -- and two
+      // at a time: all operands of both tiles are requested before the first product, and the two accumulator chains
+      // alternate on the matrix core.
+      // Wave 4 shares a SIMD -- and with it the fp64 pipe, which vector and matrix-core instructions both use -- with
+      // wave 0, whose chain through the diagonal tile is the longest job of a step unless the trailing block is large:
+      // it takes tiles only then (the first steps of a 30-keyframe window).
+      const int n_trailing = (nt - j - 1) * (nt - j) / 2 - 1;
+      const bool seven = n_trailing >= 30;
+      const int kUpd = seven ? kSolveThreads / 64 - 1 : kSolveThreads / 64 - 2;
+      int i2 = (wave == 4 && !seven) ? nt : j + 2, j2 = j + 1 + ((seven || wave < 4) ? wave - 1 : wave - 2);
+      while (i2 < nt && j2 > i2) { j2 -= i2 - j; ++i2; }
+      while (i2 < nt) {
+        double* C0 = Lt + ltile(i2, j2);
+        const double* M0 = Lt + ltile(j2, j);
+        const double* N0 = Lt + ltile(i2, j);
+        j2 += kUpd;
+        while (i2 < nt && j2 > i2) { j2 -= i2 - j; ++i2; }
+        const bool two = i2 < nt;
+        double* C1 = two ? Lt + ltile(i2, j2) : C0;
+        const double* M1 = two ? Lt + ltile(j2, j) : M0;
+        const double* N1 = two ? Lt + ltile(i2, j) : N0;
+        if (two) {
+          j2 += kUpd;
+          while (i2 < nt && j2 > i2) { j2 -= i2 - j; ++i2; }
         }
+        double a0[4], b0[4], a1[4], b1[4];
+        v4d acc0 = tile_load_t(C0, lane), acc1 = tile_load_t(C1, lane);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const int o = (kk * 4 + (lane >> 4)) * TB + (lane & 15);
+          a0[kk] = -M0[o]; b0[kk] = N0[o];
+          a1[kk] = -M1[o]; b1[kk] = N1[o];
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[kk], b0[kk], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kk], b1[kk], acc1, 0, 0, 0);
+        }
+        tile_store_t(C0, acc0, lane);
+        if (two) tile_store_t(C1, acc1, lane);
       }
     }
+    HIPBA_LAP(2);
     __syncthreads();
+    HIPBA_LAP(3);
   }
+#ifdef HIPBA_PHASE_TIMING
+  if (t == 0 || t == 64) for (int i = 0; i < 4; ++i) g_ticks[8 * (1 + (t >> 6)) + i] = (unsigned long long)tq[i];
+#endif
   HIPBA_TICK(3);
   HIPBA_CYCLES(6);
   if (fail) {
