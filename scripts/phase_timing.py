@@ -55,6 +55,7 @@ def main():
         tt = np.frombuffer(buf, dtype=np.uint64).reshape(n, 8).astype(np.int64)
         print("factor loop, shader cycles: wave 0 panel %d, wait %d, diagonal tile %d, wait %d; wave 1 panel %d, wait %d, trailing %d, wait %d" % (
             *tt[1][:4], *tt[2][:4]))
+        print("   wave 4: panel %d, wait %d, forward blocks (and tiles) %d, wait %d" % tuple(tt[5][:4]))
         t = tt[0]
         print("reduced_solve %.1f us: gradient check %.2f, load %.2f, factor %.2f, back sweep %.2f us" % (
             1e3 * ms, *[(t[i + 1] - t[i]) * 10e-3 for i in range(4)]))

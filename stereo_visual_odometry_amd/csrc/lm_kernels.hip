@@ -2078,6 +2078,58 @@ __global__ __launch_bounds__(kSolveThreads) void k_window_solve_tiles(DevP P, Lm
   HIPBA_CYCLES(5);
   if (wave == 0 && !tile_cholesky_inverse(Lt, nullptr, 0, lane) && lane == 0) fail = 1;
   __syncthreads();
+  auto wave_sync = [] {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  // sum over the four lanes of a quad, in every lane: two DPP quad permutes per 32-bit half (no LDS round trip)
+  auto quad_xor = [](double v, int ctrl_is_xor2) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int plo = ctrl_is_xor2 ? __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xf, 0xf, false)
+                                 : __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xf, 0xf, false);
+    const int phi = ctrl_is_xor2 ? __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xf, 0xf, false)
+                                 : __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xf, 0xf, false);
+    return __hiloint2double(phi, plo);
+  };
+  auto groups_sum = [&](double v) {
+    v += quad_xor(v, 0);
+    v += quad_xor(v, 1);
+    return v;
+  };
+  // Forward substitution inside the factor loop (zb holds b on entry and z = L^-1 b at the end).  In step j -- the
+  // panel of column j is final, and so was that of column j - 1 a step earlier:
+  //   one wave (forward_chain): b_j -= L(j, j-1) z_(j-1), the last update b_j lacks, then z_j = L(j,j)^-1 b_j;
+  //   the updating waves (forward_rows), beside their tiles: b_i -= L(i, j-1) z_(j-1) for the rows i > j, a row per wave.
+  // Every block of b has one writer per step, and z_(j-1) is not written in step j.
+  // lane (p = lane >> 2, g = lane & 3): (T v)(p), the quad's four partial sums combined in every lane
+  auto tile_times = [&](const double* T, const double* v) {
+    const int p = lane >> 2, g = lane & 3;
+    double acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc += T[(4 * g + q) * TB + p] * v[4 * g + q];
+    return groups_sum(acc);
+  };
+  auto forward_chain = [&](int j) {
+    const int p = lane >> 2, g = lane & 3;
+    if (j > 0) {
+      const double r = tile_times(Lt + ltile(j, j - 1), zb + TB * (j - 1));
+      const double cur = zb[TB * j + p];
+      wave_sync();
+      if (g == 0) zb[TB * j + p] = cur - r;
+      wave_sync();
+    }
+    const double zj = tile_times(Lt + ltile(j, j), zb + TB * j);   // (the diagonal tile holds its inverse)
+    wave_sync();                                                     // every lane has read b_j
+    if (g == 0) zb[TB * j + p] = zj;
+  };
+  auto forward_rows = [&](int j, int first, int step) {
+    const int p = lane >> 2, g = lane & 3;
+    for (int i = j + 1 + first; i < nt; i += step) {
+      const double r = tile_times(Lt + ltile(i, j - 1), zb + TB * (j - 1));
+      if (g == 0) zb[TB * i + p] -= r;
+    }
+  };
 #ifdef HIPBA_PHASE_TIMING
   long long tq[4] = {0, 0, 0, 0}, tprev = clock64();
 #define HIPBA_LAP(i) do { const long long now_ = clock64(); tq[i] += now_ - tprev; tprev = now_; } while (0)
@@ -2115,6 +2167,9 @@ __global__ __launch_bounds__(kSolveThreads) void k_window_solve_tiles(DevP P, Lm
         if (!tile_cholesky_inverse(C, nullptr, 0, lane) && lane == 0) fail = 1;
         __builtin_amdgcn_s_setprio(0);
       }
+      // (steps with a large trailing block leave this wave waiting: it takes the forward chain there; in the others
+      // the wave without tiles does)
+      if ((nt - j - 1) * (nt - j) / 2 - 1 >= 30) forward_chain(j);
     } else {
       // this wave's tiles of the trailing block: every seventh of the row-by-row list (row i2 holds j2 = j + 1 .. i2),
       // walked directly -- scanning the whole list with a modulo test per tile cost as much as the products -- and two
@@ -2125,8 +2180,11 @@ __global__ __launch_bounds__(kSolveThreads) void k_window_solve_tiles(DevP P, Lm
       // it takes tiles only then (the first steps of a 30-keyframe window).
       const int n_trailing = (nt - j - 1) * (nt - j) / 2 - 1;
       const bool seven = n_trailing >= 30;
+      if (wave == 4 && !seven) forward_chain(j);
       const int kUpd = seven ? kSolveThreads / 64 - 1 : kSolveThreads / 64 - 2;
-      int i2 = (wave == 4 && !seven) ? nt : j + 2, j2 = j + 1 + ((seven || wave < 4) ? wave - 1 : wave - 2);
+      const int widx = (seven || wave < 4) ? wave - 1 : wave - 2;  // this wave's place among the updating ones
+      if (j > 0 && (seven || wave != 4)) forward_rows(j, widx, kUpd);
+      int i2 = (wave == 4 && !seven) ? nt : j + 2, j2 = j + 1 + widx;
       while (i2 < nt && j2 > i2) { j2 -= i2 - j; ++i2; }
       while (i2 < nt) {
         double* C0 = Lt + ltile(i2, j2);
@@ -2164,7 +2222,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_window_solve_tiles(DevP P, Lm
     HIPBA_LAP(3);
   }
 #ifdef HIPBA_PHASE_TIMING
-  if (t == 0 || t == 64) for (int i = 0; i < 4; ++i) g_ticks[8 * (1 + (t >> 6)) + i] = (unsigned long long)tq[i];
+  if (t == 0 || t == 64 || t == 256) for (int i = 0; i < 4; ++i) g_ticks[8 * (1 + (t >> 6)) + i] = (unsigned long long)tq[i];
 #endif
   HIPBA_TICK(3);
   HIPBA_CYCLES(6);
@@ -2172,51 +2230,13 @@ __global__ __launch_bounds__(kSolveThreads) void k_window_solve_tiles(DevP P, Lm
     if (t == 0) st->solve_failed = 1;
     return;
   }
-  // L z = b, then L^T y = z, by wave 0: lane (p = lane >> 2, g = lane & 3) sums four columns of a 16x16
-  // matrix-vector product, and the four partial sums -- neighbouring lanes -- meet through two quad permutes.
-  // The diagonal tiles hold their inverses.
+
+  // L^T y = z by wave 0 (z = L^-1 b was formed inside the factor loop): lane (p = lane >> 2, g = lane & 3) sums four
+  // columns of a 16x16 matrix-vector product, and the four partial sums -- neighbouring lanes -- meet through two quad
+  // permutes.  The diagonal tiles hold their inverses.
   if (wave == 0) {
     const int p = lane >> 2, g = lane & 3;
-    auto wave_sync = [] {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    };
-    // sum over the four lanes of a quad, in every lane: two DPP quad permutes per 32-bit half (no LDS round trip)
-    auto quad_xor = [](double v, int ctrl_is_xor2) {
-      const int lo = __double2loint(v), hi = __double2hiint(v);
-      const int plo = ctrl_is_xor2 ? __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xf, 0xf, false)
-                                   : __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xf, 0xf, false);
-      const int phi = ctrl_is_xor2 ? __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xf, 0xf, false)
-                                   : __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xf, 0xf, false);
-      return __hiloint2double(phi, plo);
-    };
-    auto groups_sum = [&](double v) {
-      v += quad_xor(v, 0);
-      v += quad_xor(v, 1);
-      return v;
-    };
     double* vb = zb + TB * nt;  // 16 words: the vector a diagonal tile's inverse is applied to
-    for (int i = 0; i < nt; ++i) {
-      double acc = 0.0;
-#pragma unroll 4
-      for (int j = 0; j < i; ++j) {
-        const double* T = Lt + ltile(i, j);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc += T[(4 * g + q) * TB + p] * zb[TB * j + 4 * g + q];
-      }
-      const double v = zb[TB * i + p] - groups_sum(acc);   // every lane of the quad holds v(p)
-      if (g == 0) vb[p] = v;
-      wave_sync();
-      const double* D = Lt + ltile(i, i);
-      double zi = 0.0;
-      // z(p) = sum_q Linv(p, q) v(q)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) zi += D[(4 * g + q) * TB + p] * vb[4 * g + q];
-      zi = groups_sum(zi);
-      if (g == 0) zb[TB * i + p] = zi;
-      wave_sync();
-    }
     for (int i = nt - 1; i >= 0; --i) {
       double acc = 0.0;
 #pragma unroll 4
