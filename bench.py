@@ -247,18 +247,24 @@ def secondary_measurements(solver, with_cpu, threads):
     out = {}
     opts = hipba.reference_production_options()
     wins = [scenes.kitti_like_window(1000 + i)[0] for i in range(8)]
-    solver.solve(wins[0].copy(), opts, log=False)  # warm-up
-    t, iters = [], []
+    # one untimed pass over the windows first: the handle's device arena and pinned staging buffer grow to the largest
+    # window they have seen and stay there, which is the state a sequence is in after its first few windows
     for w in wins:
-        p = w.copy()
-        t0 = time.perf_counter()
-        s = solver.solve(p, opts, log=False)
-        t.append(time.perf_counter() - t0)
-        iters.append(s["num_iterations"] - 1)
-    kw = {"ms_per_window": 1e3 * float(np.mean(t)), "lm_iterations_per_window": float(np.mean(iters)),
+        solver.solve(w.copy(), opts, log=False)
+    t, iters = [], []
+    for rep in range(3):
+        for w in wins:
+            p = w.copy()
+            t0 = time.perf_counter()
+            s = solver.solve(p, opts, log=False)
+            t.append(time.perf_counter() - t0)
+            iters.append(s["num_iterations"] - 1)
+    kw = {"ms_per_window": 1e3 * float(np.mean(t)), "ms_per_window_median": 1e3 * float(np.median(t)),
+          "lm_iterations_per_window": float(np.mean(iters)),
           "lm_iterations_per_s": float(np.sum(iters) / np.sum(t)),
           "workload": "30 keyframes, ~4000 landmarks, ~25k observations, production semantics "
-                      "(first frame constant, 300 iteration budget), host upload included; mean of 8 windows"}
+                      "(first frame constant, 300 iteration budget), host upload included; mean of 8 windows x 3 passes "
+                      "after one untimed pass (buffers at their high-water mark)"}
     # per-kernel durations on window 0, resident
     w0 = wins[0]
     dp = solver.upload(w0)

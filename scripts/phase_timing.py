@@ -57,6 +57,7 @@ def main():
             *tt[1][:4], *tt[2][:4]))
         print("   wave 4: panel %d, wait %d, forward blocks (and tiles) %d, wait %d" % tuple(tt[5][:4]))
         t = tt[0]
+        print("   start -> matrix words requested %.2f us, -> gradient test done %.2f us" % ((t[7] - t[0]) * 10e-3, (t[1] - t[7]) * 10e-3))
         print("reduced_solve %.1f us: gradient check %.2f, load %.2f, factor %.2f, back sweep %.2f us" % (
             1e3 * ms, *[(t[i + 1] - t[i]) * 10e-3 for i in range(4)]))
         print("factor phase: %d shader cycles in %.2f us -> %.0f MHz" % (t[6] - t[5], (t[3] - t[2]) * 10e-3,

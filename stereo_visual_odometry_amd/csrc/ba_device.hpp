@@ -154,6 +154,10 @@ struct DevP {
   double* fw;                     // [n_pm_obs] sqrt(rho') of every observation (robust loss only)
   double* cam_tab;                // [18 * n_act_poses] R^T (9), R^T t (3), scale_c (6) of every variable pose
   const WinDesc* wd;
+  // One-window launches carry the window's descriptor in the kernel arguments too (has_wd0): a kernel then starts
+  // its first data loads without a round trip to memory for the descriptor.  Read through win_desc().
+  WinDesc wd0;
+  int has_wd0;
   WinState* ws;
   // work arrays
   double* U;        // [36*n_act_poses] scaled camera blocks
@@ -173,12 +177,19 @@ struct DevP {
   double* partial;  // [2 banks][kPartialStride * n_blocks]
   double* gpart;    // [2 * n_blk_pm] landmark gradient max / sum of squares per PM block
   double* wsum;     // [8 * n_windows] per-window sums handed to the all-reduce of sharded solves
+  int* tile_src;    // one small window of 48 unknowns and more: where every word of the in-LDS tile image of S comes
+                    // from in the packed S (k_window_solve_tiles writes it in a solve's first pass, reads it after)
   int sharded;      // 1 when this rank holds only a shard of the window's landmarks
   int dest_owned;   // small windows: the elimination lets every lane own one block of S and find its products itself
                     // (no pair or run lists were built: see point_schur_body, MODE 4)
   hipba_iteration* log;
   int log_cap;      // entries per window
 };
+
+__device__ __forceinline__ WinDesc win_desc(const DevP& P, int w) {
+  if (P.has_wd0) return P.wd0;
+  return P.wd[w];
+}
 
 // packed upper block-triangular index of block (r, c), r <= c, for n block rows
 __host__ __device__ __forceinline__ long long tri_index(int r, int c, int n) {

@@ -1042,6 +1042,7 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   work.add(&P.partial, (size_t)2 * kPartialStride * std::max(n_blocks, 1));
   work.add(&P.gpart, (size_t)2 * std::max(n_blk_pm, 1));
   work.add(&P.wsum, (size_t)8 * nw);
+  if (nw == 1 && 6 * max_ncam <= kSmallMaxN) work.add(&P.tile_src, (size_t)(kSmallMaxN / 16) * (kSmallMaxN / 16 + 1) / 2 * 256);
   work.add(&P.log, (size_t)std::max(log_cap, 1) * nw);
   if (staged) { work.add(&P.prec, 16 * npp); work.add(&P.fw, (size_t)n_pm_obs); work.add(&P.cam_tab, 18 * ns); }
   char* big_base_dummy = nullptr;
@@ -1075,6 +1076,8 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   P.cm_start = d_cm_start; P.cm_dp = d_cm_dp; P.cm_uv = d_cm_uv;
   P.obs_pose = d_obs_pose; P.obs_dp = d_obs_dp; P.obs_uv = d_obs_uv; P.pp_obs_start = d_pp_start;
   P.blocks = d_blocks; P.pairs = d_pairs; P.wd = d_wd; P.runs = d_runs;
+  P.has_wd0 = nw == 1 ? 1 : 0;
+  if (nw == 1) P.wd0 = wd[0];
   P.pair_obs = d_pair_obs; P.pair_pt = d_pair_pt; P.chunk_start = d_chunk_start;
   P.n_chunks = staged ? (int)(chunk_start.size() / 2) : 0;
   P.dest_owned = dest_owned ? 1 : 0;
@@ -1372,12 +1375,12 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
       }
     }
     if (small && !sharded) {
-      HIPBA_HIP(launch_window_solve_small(P, lm, max_n, 1, s));  // also forms the candidate poses
+      HIPBA_HIP(launch_window_solve_small(P, lm, max_n, 1, iter == 1 ? 1 : 2, s));  // also forms the candidate poses
     } else {
       if (!sharded) HIPBA_HIP(launch_window_gradient(P, lm, kFused, s));
       if (small) {
         // sharded small window: gradient already decided; the LDS solver repeats the (idempotent) check
-        HIPBA_HIP(launch_window_solve_small(P, lm, max_n, 0, s));
+        HIPBA_HIP(launch_window_solve_small(P, lm, max_n, 0, 0, s));
       } else if (solver == HIPBA_LINEAR_PCG) {
         HIPBA_HIP(big_solve_pcg(P, R->big, o.pcg_max_iterations, o.pcg_tolerance, s));
       } else {
@@ -1420,6 +1423,7 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
         const int want = iter - lag;
         double deadline = 0.0;
         for (long long spins = 0; (*word >> 1) != want; ++spins) {
+          __builtin_ia32_pause();
           if ((spins & 0xfff) == 0xfff) {
             const double now = now_s();
             if (deadline == 0.0) deadline = now + 10.0;
@@ -2222,8 +2226,10 @@ int hipba_time_kernel(hipba_handle h, hipba_device_problem dp, const hipba_optio
       HIPBA_HIP(launch_point_schur(P, lm, small_ncam, schur_parts, s));
       return HIPBA_OK;
     };
+    int solves_done = 0;
     auto solve_once = [&]() -> int {
-      if (small) HIPBA_HIP(launch_window_solve_small(P, lm, max_n, 0, s));
+      // (as in a solve: the first launch writes the table of tile sources, the others read it)
+      if (small) HIPBA_HIP(launch_window_solve_small(P, lm, max_n, 0, solves_done++ == 0 ? 1 : 2, s));
       else if (o.linear_solver == HIPBA_LINEAR_PCG) HIPBA_HIP(big_solve_pcg(P, dp->big, o.pcg_max_iterations, o.pcg_tolerance, s));
       else HIPBA_HIP(big_solve_cholesky(P, dp->big, dp->env_first.empty() ? nullptr : dp->env_first.data(), s));
       return HIPBA_OK;

@@ -21,7 +21,8 @@ hipError_t launch_point_colnorm(const DevP& P, const LmParams& lm, hipStream_t s
 hipError_t launch_init_reduced(const DevP& P, const LmParams& lm, int owner, hipStream_t s);
 hipError_t launch_point_schur(const DevP& P, const LmParams& lm, int small_ncam, int parts, hipStream_t s);
 hipError_t launch_small_linearize(const DevP& P, const LmParams& lm, int small_ncam, int parts, hipStream_t s);
-hipError_t launch_window_solve_small(const DevP& P, const LmParams& lm, int max_n, int fuse_pose_update, hipStream_t s);
+hipError_t launch_window_solve_small(const DevP& P, const LmParams& lm, int max_n, int fuse_pose_update, int table_mode,
+                                     hipStream_t s);
 hipError_t launch_window_gradient(const DevP& P, const LmParams& lm, int mode, hipStream_t s);
 // with_cost: the pass also evaluates the cost at the candidate point (no launch_cost(which = 1) after it); the
 // candidate poses must have been formed before, and the problem must have no landmark that spans several blocks

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(kBlock) void k_cost(DevP P, LmParams lm, int blk_of
   for (int k = 0; k < kCostGroup; ++k) {
     acc[2 * k] = 0.0; acc[2 * k + 1] = 0.0;
     if (live[k]) {
-      const CameraK K = P.wd[d[k].window].K;
+      const CameraK K = win_desc(P, d[k].window).K;
       double r[2];
       residual_only(K, pose[k], pt[k], uv[k].x, uv[k].y, r);
       const double s = r[0] * r[0] + r[1] * r[1];
@@ -199,7 +199,7 @@ __device__ __forceinline__ void init_reduced_pose(const DevP& P, const LmParams&
   const int w = P.pose_window[c];
   WinState* st = P.ws + w;
   if (!st->active) return;
-  const WinDesc wd = P.wd[w];
+  const WinDesc wd = win_desc(P, w);
   const int slot = g - wd.cam_base;
   double* Sb = P.S + wd.S_off + 36ll * tri_index(slot, slot, wd.ncam);
   const double* U = P.U + 36ll * g;
@@ -281,7 +281,7 @@ __device__ __forceinline__ void camera_blocks_body(const DevP& P, const LmParams
   const WinState* st = P.ws + w;
   if (!st->active) return;
   const int sel = st->sel;
-  const CameraK K = P.wd[w].K;
+  const CameraK K = win_desc(P, w).K;
   double pose[7];
 #pragma unroll
   for (int i = 0; i < 7; ++i) pose[i] = P.poses[sel][7ll * c + i];
@@ -366,7 +366,7 @@ __device__ __forceinline__ void point_colnorm_body(const DevP& P, const LmParams
   const WinState* st = P.ws + d.window;
   if (!st->active || d.pad) return;  // (a piece of a long landmark: k_long_point's)
   const int sel = st->sel;
-  const CameraK K = P.wd[d.window].K;
+  const CameraK K = win_desc(P, d.window).K;
   const int t = threadIdx.x;
   int pp = -1;
   if (t < d.n_obs) {
@@ -558,8 +558,8 @@ __device__ __forceinline__ void point_schur_body(const DevP& P, const LmParams& 
     if (OWNED) dg = bid - wp * dgroups;
     w = wp / parts;
     const int part = wp - w * parts;
-    blk = P.wd[w].pm_blk_begin + part;
-    blk_end = P.wd[w].pm_blk_end;
+    blk = win_desc(P, w).pm_blk_begin + part;
+    blk_end = win_desc(P, w).pm_blk_end;
     blk_step = parts;
     if (blk >= blk_end) return;
   } else {
@@ -567,7 +567,7 @@ __device__ __forceinline__ void point_schur_body(const DevP& P, const LmParams& 
   }
   const WinState* st = P.ws + w;
   if (!st->active) return;
-  const WinDesc wd = P.wd[w];
+  const WinDesc wd = win_desc(P, w);
   const int sel = st->sel;
   const double inv_radius = 1.0 / st->radius;
   // owned destinations: this lane's block (own_i, own_j) of S, and which of the own_k lane groups of that block it is
@@ -898,10 +898,10 @@ __global__ __launch_bounds__(kBlock) void k_schur_gather(DevP P, LmParams lm) {
   const int chunk = blockIdx.x * (kBlock / 64) + wave;
   if (chunk >= P.n_chunks) return;  // whole waves leave; nothing below synchronises across waves
   double* sT = smem + wave * kGatherLds;
-  const CameraK K = P.wd[0].K;
-  const int ncam = P.wd[0].ncam;
-  const double* cam_tab = P.cam_tab + 18ll * P.wd[0].cam_base;
-  double* S = P.S + P.wd[0].S_off;
+  const CameraK K = win_desc(P, 0).K;
+  const int ncam = win_desc(P, 0).ncam;
+  const double* cam_tab = P.cam_tab + 18ll * win_desc(P, 0).cam_base;
+  double* S = P.S + win_desc(P, 0).S_off;
   const bool robust = lm.loss != HIPBA_LOSS_NONE;
   const int e = lane < 36 ? lane : 0;
   const long long q0 = P.chunk_start[2 * chunk], q1 = P.chunk_start[2 * chunk + 1];
@@ -915,7 +915,7 @@ __global__ __launch_bounds__(kBlock) void k_schur_gather(DevP P, LmParams lm) {
   const int er = e / 6, ec = e % 6;
   // word of the right-hand side a lane sums in a diagonal destination (see the products below), or -1
   const int e_rhs = (lane < 36 && er >= 1 && er <= 3 && ec < er) ? er * (er - 1) / 2 + ec : -1;
-  double* const bw = P.b + 6ll * P.wd[0].cam_base;
+  double* const bw = P.b + 6ll * win_desc(P, 0).cam_base;
   auto flush = [&]() {
     if (cur >= 0 && lane < 36) {
       // (a diagonal block is symmetric: the packed matrix, which keeps all of it, gets the words that carry the
@@ -1111,7 +1111,7 @@ __global__ __launch_bounds__(kBlock) void k_backsub(DevP P, LmParams lm, double*
   const WinState* st = P.ws + w;
   if (!st->active || st->solve_failed) return;
   if (d.kind == 0 && d.pad) return;  // a piece of a long landmark: k_long_point's
-  const WinDesc wd = P.wd[w];
+  const WinDesc wd = win_desc(P, w);
   const int sel = st->sel;
   const int t = threadIdx.x;
   const bool live = t < d.n_obs;
@@ -1239,7 +1239,7 @@ __global__ __launch_bounds__(kBlock) void k_long_point(DevP P, LmParams lm) {
   const WinState* st = P.ws + w;
   if (!st->active) return;
   if (PHASE == 2 && st->solve_failed) return;
-  const WinDesc wd = P.wd[w];
+  const WinDesc wd = win_desc(P, w);
   const int sel = st->sel;
   const int t = threadIdx.x, pp = L.pp;
   const double p[3] = {P.points[sel][3ll * pp], P.points[sel][3ll * pp + 1], P.points[sel][3ll * pp + 2]};
@@ -1387,7 +1387,7 @@ __global__ __launch_bounds__(kBlock) void k_long_point(DevP P, LmParams lm) {
 // workgroup (any size that is a multiple of 64; red: two words per wave)
 __device__ __forceinline__ void pose_update_window(const DevP& P, int w, double* red) {
   WinState* st = P.ws + w;
-  const WinDesc wd = P.wd[w];
+  const WinDesc wd = win_desc(P, w);
   const int sel = st->sel;
   double acc[2] = {0.0, 0.0};
   for (int c = wd.pose_begin + threadIdx.x; c < wd.pose_end; c += blockDim.x) {
@@ -1438,7 +1438,7 @@ constexpr int kWsum = 8;  // doubles of P.wsum per window
 __global__ __launch_bounds__(kBlock) void k_window_init(DevP P, LmParams lm, int mode, int zero_S) {
   __shared__ double red[3 * 4];
   const int w = blockIdx.x;
-  const WinDesc wd = P.wd[w];
+  const WinDesc wd = win_desc(P, w);
   WinState* st = P.ws + w;
   if (zero_S) {
     double2* Sw = reinterpret_cast<double2*>(P.S + wd.S_off);
@@ -1508,18 +1508,33 @@ __global__ __launch_bounds__(kBlock) void k_window_init(DevP P, LmParams lm, int
 // gradient norms of the fresh linearisation + gradient-tolerance test (Ceres checks it when an
 // iteration that moved x is finalised; the norms only exist once the blocks have been rebuilt).
 // wsum slots: [0] landmark max (max-reduced across ranks), [1] landmark sum of squares.
-__device__ void window_gradient_check(const DevP& P, const LmParams& lm, const WinDesc& wd, WinState* st, double* red,
-                                      int mode) {
-  const int w = (int)(st - P.ws);
-  double gm = 0.0;
-  double g2[1] = {0.0};
+// In two halves, so that a caller can put loads of its own between the words this test reads and the reductions
+// (four barriers) that follow: window_gradient_partials returns the thread's share, window_gradient_finish does the rest.
+struct GradientPartials { double gm, g2, pm, p2; };
+__device__ __forceinline__ GradientPartials window_gradient_partials(const DevP& P, const WinDesc& wd, int mode) {
+  GradientPartials v{0.0, 0.0, 0.0, 0.0};
   if (mode != kDecide) {
 #pragma unroll 8
     for (int b = wd.pm_blk_begin + threadIdx.x; b < wd.pm_blk_end; b += blockDim.x) {
       const double2 gp = reinterpret_cast<const double2*>(P.gpart)[b];  // (max, sum of squares) of block b
-      gm = fmax(gm, gp.x);
-      g2[0] += gp.y;
+      v.gm = fmax(v.gm, gp.x);
+      v.g2 += gp.y;
     }
+  }
+  if (mode != kReduce) {
+    for (int g = wd.cam_base + threadIdx.x; g < wd.cam_base + wd.ncam; g += blockDim.x) {
+      v.pm = fmax(v.pm, P.yc[6ll * g]);
+      v.p2 += P.yc[6ll * g + 1];
+    }
+  }
+  return v;
+}
+__device__ __forceinline__ void window_gradient_finish(const DevP& P, const LmParams& lm, const WinDesc& wd, WinState* st,
+                                                       double* red, int mode, GradientPartials v) {
+  const int w = (int)(st - P.ws);
+  double gm = v.gm;
+  double g2[1] = {v.g2};
+  if (mode != kDecide) {
     gm = block_max(gm, red);
     block_sum<1>(g2, red);
     if (mode == kReduce) {
@@ -1527,12 +1542,8 @@ __device__ void window_gradient_check(const DevP& P, const LmParams& lm, const W
       return;
     }
   }
-  double pm = 0.0;
-  double p2[1] = {0.0};
-  for (int g = wd.cam_base + threadIdx.x; g < wd.cam_base + wd.ncam; g += blockDim.x) {
-    pm = fmax(pm, P.yc[6ll * g]);
-    p2[0] += P.yc[6ll * g + 1];
-  }
+  double pm = v.pm;
+  double p2[1] = {v.p2};
   pm = block_max(pm, red);
   block_sum<1>(p2, red);
   if (threadIdx.x == 0) {
@@ -1552,6 +1563,10 @@ __device__ void window_gradient_check(const DevP& P, const LmParams& lm, const W
   }
   __syncthreads();
 }
+__device__ void window_gradient_check(const DevP& P, const LmParams& lm, const WinDesc& wd, WinState* st, double* red,
+                                      int mode) {
+  window_gradient_finish(P, lm, wd, st, red, mode, window_gradient_partials(P, wd, mode));
+}
 
 // end of an iteration: reduce the per-block partials and run Ceres' acceptance logic
 // (TrustRegionMinimizer::Minimize, LevenbergMarquardtStrategy::StepAccepted/Rejected/IsInvalid)
@@ -1560,7 +1575,7 @@ __device__ __forceinline__ void window_control_body(const DevP& P, const LmParam
   const int w = blockIdx.x;
   WinState* st = P.ws + w;
   if (!st->active) return;
-  const WinDesc wd = P.wd[w];
+  const WinDesc wd = win_desc(P, w);
   const bool failed = st->solve_failed != 0;
   // acc: 0 model term, 1 point step^2, 2 point x^2, 3 candidate cost, 4 bad flag
   double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
@@ -1687,7 +1702,7 @@ __global__ __launch_bounds__(kWideBlock) void k_window_control(DevP P, LmParams 
   __syncthreads();  // the decision thread 0 has just written
   const WinState* st = P.ws + blockIdx.x;
   if (!*reinterpret_cast<const volatile int*>(&st->active)) return;
-  const WinDesc wd = P.wd[blockIdx.x];
+  const WinDesc wd = win_desc(P, blockIdx.x);
   double2* Sw = reinterpret_cast<double2*>(P.S + wd.S_off);
   const long long n2 = 18ll * ((long long)wd.ncam * (wd.ncam + 1) / 2);
   for (long long i = threadIdx.x; i < n2; i += blockDim.x) Sw[i] = make_double2(0.0, 0.0);
@@ -1813,7 +1828,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_window_solve_small(DevP P, Lm
   WinState* st = P.ws + w;
   if (!st->active) return;
   HIPBA_TICK(0);
-  const WinDesc wd = P.wd[w];
+  const WinDesc wd = win_desc(P, w);
   window_gradient_check(P, lm, wd, st, red, kFused);
   HIPBA_TICK(1);
   if (!st->active) return;
@@ -2018,7 +2033,10 @@ __global__ __launch_bounds__(kSolveThreads) void k_window_solve_small(DevP P, Lm
 // matrix-vector products by wave 0 with the tiles' inverses.  The 6x6-block version above walks 29 block columns of
 // ~5.6 k cycles each for such a window; this one 11 tile columns of ~7 k.
 constexpr int kTileSolveMinN = 48;  // windows from this size on take this kernel (smaller ones: the 6x6-block kernel above)
-__global__ __launch_bounds__(kSolveThreads) void k_window_solve_tiles(DevP P, LmParams lm, int fuse_pose_update) {
+// table_mode (P.tile_src): 0 the source offsets of the tile image are computed, 1 computed and written to the table,
+// 2 read from it (the offsets depend on the number of poses only; computing them is two divisions by six and a
+// triangular index per word, 39 times per lane -- 7 us of the kernel's 12 us before the factorisation).
+__global__ __launch_bounds__(kSolveThreads) void k_window_solve_tiles(DevP P, LmParams lm, int fuse_pose_update, int table_mode) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* red = smem;                                  // [8]
   int& fail = *reinterpret_cast<int*>(smem + 8);
@@ -2026,7 +2044,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_window_solve_tiles(DevP P, Lm
   WinState* st = P.ws + w;
   if (!st->active) return;
   HIPBA_TICK(0);
-  const WinDesc wd = P.wd[w];
+  const WinDesc wd = win_desc(P, w);
   const int nb = wd.ncam;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const double* Sg = P.S + wd.S_off;
@@ -2040,29 +2058,43 @@ __global__ __launch_bounds__(kSolveThreads) void k_window_solve_tiles(DevP P, Lm
   // test: 32 scattered stores per lane behind a data-dependent walk of the block rows.)
   constexpr int kPre = (kSmallMaxN / TB) * (kSmallMaxN / TB + 1) / 4;  // tiles of the largest window / 2
   const int n = 6 * nb, nt = (n + TB - 1) / TB, ntl = nt * (nt + 1) / 2;
+  // (the gradient test's own few words first: the memory pipe returns in order, so its reductions need not wait for
+  // the matrix)
+  const GradientPartials gpv = window_gradient_partials(P, wd, kFused);
   const int half = t >> 8, ent = t & 255, ep = ent & 15, eq = ent >> 4;
   double pre[kPre];
   {
     int ti = 0, tj = half;  // tile (ti, tj) of this half's first tile: linear index `half`
     while (tj > ti) { tj -= ti + 1; ++ti; }
+    // source of a word: its offset in the packed matrix, or -1 (one: the diagonal of the padding) or -2 (zero)
+    if (table_mode == 2) {
+      int src[kPre];
 #pragma unroll
-    for (int k = 0; k < kPre; ++k) {
-      double v = 0.0;
-      if (2 * k + half < ntl) {
-        const int r = TB * ti + ep, cc = TB * tj + eq;
-        if (r >= n) v = r == cc ? 1.0 : 0.0;
-        else if (r >= cc) {
-          const int bi = cc / 6, bj = r / 6;
-          const int blk = bi * nb - bi * (bi - 1) / 2 + (bj - bi);
-          v = Sg[36ll * blk + (bi == bj ? 6 * (r - 6 * bi) + (cc - 6 * bi) : 6 * (cc - 6 * bi) + (r - 6 * bj))];
+      for (int k = 0; k < kPre; ++k) src[k] = 2 * k + half < ntl ? P.tile_src[(2 * k + half) * kTile + ent] : -2;
+#pragma unroll
+      for (int k = 0; k < kPre; ++k) pre[k] = src[k] >= 0 ? Sg[src[k]] : (src[k] == -1 ? 1.0 : 0.0);
+    } else {
+#pragma unroll
+      for (int k = 0; k < kPre; ++k) {
+        int src = -2;
+        if (2 * k + half < ntl) {
+          const int r = TB * ti + ep, cc = TB * tj + eq;
+          if (r >= n) src = r == cc ? -1 : -2;
+          else if (r >= cc) {
+            const int bi = cc / 6, bj = r / 6;
+            const int blk = bi * nb - bi * (bi - 1) / 2 + (bj - bi);
+            src = 36 * blk + (bi == bj ? 6 * (r - 6 * bi) + (cc - 6 * bi) : 6 * (cc - 6 * bi) + (r - 6 * bj));
+          }
+          if (table_mode == 1) P.tile_src[(2 * k + half) * kTile + ent] = src;
         }
+        pre[k] = src >= 0 ? Sg[src] : (src == -1 ? 1.0 : 0.0);
+        tj += 2;
+        while (tj > ti) { tj -= ti + 1; ++ti; }
       }
-      pre[k] = v;
-      tj += 2;
-      while (tj > ti) { tj -= ti + 1; ++ti; }
     }
   }
-  window_gradient_check(P, lm, wd, st, red, kFused);
+  HIPBA_TICK(7);
+  window_gradient_finish(P, lm, wd, st, red, kFused, gpv);
   HIPBA_TICK(1);
   if (!st->active) return;
   if (nb == 0) return;
@@ -2282,7 +2314,7 @@ __global__ __launch_bounds__(kWideBlock) void k_window_gradient(DevP P, LmParams
   const int w = blockIdx.x;
   WinState* st = P.ws + w;
   if (!st->active) return;
-  window_gradient_check(P, lm, P.wd[w], st, red, mode);
+  window_gradient_check(P, lm, win_desc(P, w), st, red, mode);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2519,13 +2551,15 @@ hipError_t launch_small_linearize(const DevP& P, const LmParams& lm, int small_n
   return hipGetLastError();
 }
 
-hipError_t launch_window_solve_small(const DevP& P, const LmParams& lm, int max_n, int fuse_pose_update, hipStream_t s) {
+hipError_t launch_window_solve_small(const DevP& P, const LmParams& lm, int max_n, int fuse_pose_update, int table_mode,
+                                     hipStream_t s) {
   // development switch: HIPBA_SMALL_SOLVER_BLOCKS=1 keeps every window on the 6x6-block kernel (A/B timing)
   static const bool blocks_only = getenv("HIPBA_SMALL_SOLVER_BLOCKS") != nullptr;
   if (max_n >= kTileSolveMinN && !blocks_only) {
     const size_t nt = (size_t)(max_n + TB - 1) / TB;
     const size_t lds = (16 + nt * (nt + 1) / 2 * kTile + TB * nt + TB) * 8;
-    hipLaunchKernelGGL(k_window_solve_tiles, dim3(P.n_windows), dim3(kSolveThreads), lds, s, P, lm, fuse_pose_update);
+    hipLaunchKernelGGL(k_window_solve_tiles, dim3(P.n_windows), dim3(kSolveThreads), lds, s, P, lm, fuse_pose_update,
+                       P.tile_src && P.n_windows == 1 ? table_mode : 0);
     return hipGetLastError();
   }
   const size_t nb = (size_t)(max_n + 5) / 6;
