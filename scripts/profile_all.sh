@@ -13,7 +13,7 @@ timeout -s KILL 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_
 wl=$(grep '^workload: ' $out/run.log | sed 's/^workload: //')
 python3 scripts/summarize_sq.py $out/pmc_sq $out/issue.json "$wl" > $out/issue.txt 2>&1
 python3 scripts/summarize_pmc.py $out/pmc_fetch $out/pmc_write $out/traffic.json "$wl" > $out/traffic_summary.log 2>&1
-cp $(find $out/trace -name '*kernel_stats.csv' | head -1) $out/kernel_stats.csv
+cp $(ls -t $(find $out/trace -name '*kernel_stats.csv') | head -1) $out/kernel_stats.csv   # (the newest, should the tag be reused)
 # the raw per-dispatch files are large: keep the summaries only
 rm -rf $out/pmc_fetch $out/pmc_write $out/pmc_sq
 find $out/trace -name '*kernel_trace.csv' -size +20M -delete

@@ -223,7 +223,9 @@ namespace {
 // workgroups per window in the small-window landmark elimination: enough to fill the chip, few enough
 // that the per-workgroup flush of the LDS accumulators stays a small part of the work
 int schur_parts_for(int n_windows, int max_pm_blocks) {
-  const int want = (4096 + n_windows - 1) / std::max(1, n_windows);
+  // development switch: HIPBA_SCHUR_WORKGROUPS=<n> sets the number of workgroups a launch aims for (default 4096)
+  static const int target = [] { const char* e = getenv("HIPBA_SCHUR_WORKGROUPS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 4096; }();
+  const int want = (target + n_windows - 1) / std::max(1, n_windows);
   return std::max(1, std::min(want, max_pm_blocks));
 }
 
