@@ -154,10 +154,6 @@ struct DevP {
   double* fw;                     // [n_pm_obs] sqrt(rho') of every observation (robust loss only)
   double* cam_tab;                // [18 * n_act_poses] R^T (9), R^T t (3), scale_c (6) of every variable pose
   const WinDesc* wd;
-  // One-window launches carry the window's descriptor in the kernel arguments too (has_wd0): a kernel then starts
-  // its first data loads without a round trip to memory for the descriptor.  Read through win_desc().
-  WinDesc wd0;
-  int has_wd0;
   WinState* ws;
   // work arrays
   double* U;        // [36*n_act_poses] scaled camera blocks
@@ -185,11 +181,6 @@ struct DevP {
   hipba_iteration* log;
   int log_cap;      // entries per window
 };
-
-__device__ __forceinline__ WinDesc win_desc(const DevP& P, int w) {
-  if (P.has_wd0) return P.wd0;
-  return P.wd[w];
-}
 
 // packed upper block-triangular index of block (r, c), r <= c, for n block rows
 __host__ __device__ __forceinline__ long long tri_index(int r, int c, int n) {

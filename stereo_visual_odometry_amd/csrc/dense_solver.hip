@@ -67,13 +67,13 @@ void big_work_bind(BigWork& W, int n, int ncam, void* base) {
 // ---- packed blocks -> dense column-major lower ----------------------------------------------------
 __global__ void k_unpack_lower(DevP P, double* A, int ld) {
   if (!P.ws[0].active) return;
-  const int ncam = win_desc(P, 0).ncam;
+  const int ncam = P.wd[0].ncam;
   const int bi = blockIdx.y;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   const int nb = ncam - bi;
   if (e >= nb * 36) return;
   const int bj = bi + e / 36, ac = e % 36, a = ac / 6, c = ac % 6;
-  const double v = P.S[win_desc(P, 0).S_off + 36ll * tri_index(bi, bi, ncam) + e];
+  const double v = P.S[P.wd[0].S_off + 36ll * tri_index(bi, bi, ncam) + e];
   const int row = 6 * bj + c, col = 6 * bi + a;
   if (row >= col) A[(long long)col * ld + row] = v;
 }
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void k_pad_init(DevP P, double* A, int n, int 
   if (gid < npad && y_not_yet) reinterpret_cast<unsigned long long*>(y_not_yet)[gid] = kNotYet;
   const int col0 = blockIdx.x * kPadCols;
   const int span = ld - n;
-  const double* b = P.b + 6ll * win_desc(P, 0).cam_base;
+  const double* b = P.b + 6ll * P.wd[0].cam_base;
   for (int idx = threadIdx.x; idx < kPadCols * span; idx += blockDim.x) {
     const int col = col0 + idx / span, row = n + idx % span;
     if (col >= npad) break;
@@ -1013,7 +1013,7 @@ __global__ void k_store_solution(DevP P, const double* y, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const double v = y[i];
-  P.yc[6ll * win_desc(P, 0).cam_base + i] = v;
+  P.yc[6ll * P.wd[0].cam_base + i] = v;
   if (!isfinite(v)) P.ws[0].solve_failed = 1;
 }
 
@@ -1222,16 +1222,16 @@ __device__ void inv6_spd(const double* Ain, double* out) {
 
 __global__ void k_pcg_init(DevP P, BigWork W, PcgView v) {
   if (!P.ws[0].active) return;
-  const int ncam = win_desc(P, 0).ncam;
+  const int ncam = P.wd[0].ncam;
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= ncam) return;
-  const double* D = P.S + win_desc(P, 0).S_off + 36ll * tri_index(c, c, ncam);
+  const double* D = P.S + P.wd[0].S_off + 36ll * tri_index(c, c, ncam);
   double Mi[36];
   inv6_spd(D, Mi);
   double rz = 0.0, bb = 0.0;
   double rr[6];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) rr[i] = P.b[6ll * (win_desc(P, 0).cam_base + c) + i];
+  for (int i = 0; i < 6; ++i) rr[i] = P.b[6ll * (P.wd[0].cam_base + c) + i];
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
     double z = 0.0;
@@ -1272,11 +1272,11 @@ __global__ __launch_bounds__(256) void k_pcg_spmv(DevP P, PcgView v) {
   __shared__ double accL[7][36];
   __shared__ double yrow[6];
   if (!P.ws[0].active || v.scal[2] != 0.0) return;
-  const int ncam = win_desc(P, 0).ncam;
+  const int ncam = P.wd[0].ncam;
   const int r = blockIdx.x;
   const int t = threadIdx.x;
   const int grp = t / 36, e = t % 36;
-  const double* S = P.S + win_desc(P, 0).S_off;
+  const double* S = P.S + P.wd[0].S_off;
   double au = 0.0, al = 0.0;
   if (grp < 7) {
     const int ea = e / 6, eb = e % 6;
@@ -1382,7 +1382,7 @@ __global__ void k_pcg_finish(DevP P, PcgView v, int n) {
   if (i == 0) P.ws[0].lin_iters = (int)v.scal[3];
   if (i >= n) return;
   const double x = v.x[i];
-  P.yc[6ll * win_desc(P, 0).cam_base + i] = x;
+  P.yc[6ll * P.wd[0].cam_base + i] = x;
   if (!isfinite(x)) P.ws[0].solve_failed = 1;
 }
 

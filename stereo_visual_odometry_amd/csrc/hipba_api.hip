@@ -1078,8 +1078,6 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   P.cm_start = d_cm_start; P.cm_dp = d_cm_dp; P.cm_uv = d_cm_uv;
   P.obs_pose = d_obs_pose; P.obs_dp = d_obs_dp; P.obs_uv = d_obs_uv; P.pp_obs_start = d_pp_start;
   P.blocks = d_blocks; P.pairs = d_pairs; P.wd = d_wd; P.runs = d_runs;
-  P.has_wd0 = nw == 1 ? 1 : 0;
-  if (nw == 1) P.wd0 = wd[0];
   P.pair_obs = d_pair_obs; P.pair_pt = d_pair_pt; P.chunk_start = d_chunk_start;
   P.n_chunks = staged ? (int)(chunk_start.size() / 2) : 0;
   P.dest_owned = dest_owned ? 1 : 0;

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(kBlock) void k_cost(DevP P, LmParams lm, int blk_of
   for (int k = 0; k < kCostGroup; ++k) {
     acc[2 * k] = 0.0; acc[2 * k + 1] = 0.0;
     if (live[k]) {
-      const CameraK K = win_desc(P, d[k].window).K;
+      const CameraK K = P.wd[d[k].window].K;
       double r[2];
       residual_only(K, pose[k], pt[k], uv[k].x, uv[k].y, r);
       const double s = r[0] * r[0] + r[1] * r[1];
@@ -199,7 +199,7 @@ __device__ __forceinline__ void init_reduced_pose(const DevP& P, const LmParams&
   const int w = P.pose_window[c];
   WinState* st = P.ws + w;
   if (!st->active) return;
-  const WinDesc wd = win_desc(P, w);
+  const WinDesc wd = P.wd[w];
   const int slot = g - wd.cam_base;
   double* Sb = P.S + wd.S_off + 36ll * tri_index(slot, slot, wd.ncam);
   const double* U = P.U + 36ll * g;
@@ -273,7 +273,8 @@ __global__ void k_init_reduced(DevP P, LmParams lm, int owner) {
 // ------------------------------------------------------------------------------------------
 // fuse_init: thread 0 goes on to do k_init_reduced's work for this pose (S must have been zeroed before this
 // launch then): one launch less per iteration.
-// fuse_init 2: the same with S and b added to instead of stored (see init_reduced_pose<true>).
+// ATOMIC_INIT: the same with S and b added to instead of stored (see init_reduced_pose<true>).
+template <bool ATOMIC_INIT>
 __device__ __forceinline__ void camera_blocks_body(const DevP& P, const LmParams& lm, int g, int use_scale, int fuse_init,
                                                    double* red) {
   const int c = P.slot_pose[g];
@@ -281,7 +282,7 @@ __device__ __forceinline__ void camera_blocks_body(const DevP& P, const LmParams
   const WinState* st = P.ws + w;
   if (!st->active) return;
   const int sel = st->sel;
-  const CameraK K = win_desc(P, w).K;
+  const CameraK K = P.wd[w].K;
   double pose[7];
 #pragma unroll
   for (int i = 0; i < 7; ++i) pose[i] = P.poses[sel][7ll * c + i];
@@ -317,14 +318,14 @@ __device__ __forceinline__ void camera_blocks_body(const DevP& P, const LmParams
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) P.gc[6ll * g + i] = acc[21 + i];
-    if (fuse_init == 2) init_reduced_pose<true>(P, lm, g, 1);
+    if (ATOMIC_INIT) init_reduced_pose<true>(P, lm, g, 1);
     else if (fuse_init) init_reduced_pose(P, lm, g, 1);
   }
 }
 
 __global__ __launch_bounds__(kBlock) void k_camera_blocks(DevP P, LmParams lm, int use_scale, int fuse_init) {
   __shared__ double red[27 * 4];
-  camera_blocks_body(P, lm, blockIdx.x, use_scale, fuse_init, red);
+  camera_blocks_body<false>(P, lm, blockIdx.x, use_scale, fuse_init, red);
 }
 
 // Jacobi scaling of the pose columns, computed once at iteration 0 from the unscaled blocks
@@ -366,7 +367,7 @@ __device__ __forceinline__ void point_colnorm_body(const DevP& P, const LmParams
   const WinState* st = P.ws + d.window;
   if (!st->active || d.pad) return;  // (a piece of a long landmark: k_long_point's)
   const int sel = st->sel;
-  const CameraK K = win_desc(P, d.window).K;
+  const CameraK K = P.wd[d.window].K;
   const int t = threadIdx.x;
   int pp = -1;
   if (t < d.n_obs) {
@@ -405,7 +406,7 @@ __global__ __launch_bounds__(kBlock) void k_point_colnorm(DevP P, LmParams lm) {
 // column norms (the others) have nothing to do with each other: one launch
 __global__ __launch_bounds__(kBlock) void k_first_blocks(DevP P, LmParams lm) {
   __shared__ double sh[kBlock * 3];
-  if ((int)blockIdx.x < P.n_act_poses) camera_blocks_body(P, lm, blockIdx.x, 0, 0, sh);
+  if ((int)blockIdx.x < P.n_act_poses) camera_blocks_body<false>(P, lm, blockIdx.x, 0, 0, sh);
   else point_colnorm_body(P, lm, (int)blockIdx.x - P.n_act_poses, sh);
 }
 
@@ -558,8 +559,8 @@ __device__ __forceinline__ void point_schur_body(const DevP& P, const LmParams& 
     if (OWNED) dg = bid - wp * dgroups;
     w = wp / parts;
     const int part = wp - w * parts;
-    blk = win_desc(P, w).pm_blk_begin + part;
-    blk_end = win_desc(P, w).pm_blk_end;
+    blk = P.wd[w].pm_blk_begin + part;
+    blk_end = P.wd[w].pm_blk_end;
     blk_step = parts;
     if (blk >= blk_end) return;
   } else {
@@ -567,7 +568,7 @@ __device__ __forceinline__ void point_schur_body(const DevP& P, const LmParams& 
   }
   const WinState* st = P.ws + w;
   if (!st->active) return;
-  const WinDesc wd = win_desc(P, w);
+  const WinDesc wd = P.wd[w];
   const int sel = st->sel;
   const double inv_radius = 1.0 / st->radius;
   // owned destinations: this lane's block (own_i, own_j) of S, and which of the own_k lane groups of that block it is
@@ -844,7 +845,7 @@ __global__ __launch_bounds__(kBlock) void k_small_linearize(DevP P, LmParams lm,
   static_assert(MODE == 1 || MODE == 3 || MODE == 4, "small-window modes only");
   if ((int)blockIdx.x < P.n_act_poses) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    camera_blocks_body(P, lm, blockIdx.x, 1, 2, smem);
+    camera_blocks_body<true>(P, lm, blockIdx.x, 1, 1, smem);
   } else {
     point_schur_body<MODE>(P, lm, parts, (int)blockIdx.x - P.n_act_poses, dgroups);
   }
@@ -898,10 +899,10 @@ __global__ __launch_bounds__(kBlock) void k_schur_gather(DevP P, LmParams lm) {
   const int chunk = blockIdx.x * (kBlock / 64) + wave;
   if (chunk >= P.n_chunks) return;  // whole waves leave; nothing below synchronises across waves
   double* sT = smem + wave * kGatherLds;
-  const CameraK K = win_desc(P, 0).K;
-  const int ncam = win_desc(P, 0).ncam;
-  const double* cam_tab = P.cam_tab + 18ll * win_desc(P, 0).cam_base;
-  double* S = P.S + win_desc(P, 0).S_off;
+  const CameraK K = P.wd[0].K;
+  const int ncam = P.wd[0].ncam;
+  const double* cam_tab = P.cam_tab + 18ll * P.wd[0].cam_base;
+  double* S = P.S + P.wd[0].S_off;
   const bool robust = lm.loss != HIPBA_LOSS_NONE;
   const int e = lane < 36 ? lane : 0;
   const long long q0 = P.chunk_start[2 * chunk], q1 = P.chunk_start[2 * chunk + 1];
@@ -915,7 +916,7 @@ __global__ __launch_bounds__(kBlock) void k_schur_gather(DevP P, LmParams lm) {
   const int er = e / 6, ec = e % 6;
   // word of the right-hand side a lane sums in a diagonal destination (see the products below), or -1
   const int e_rhs = (lane < 36 && er >= 1 && er <= 3 && ec < er) ? er * (er - 1) / 2 + ec : -1;
-  double* const bw = P.b + 6ll * win_desc(P, 0).cam_base;
+  double* const bw = P.b + 6ll * P.wd[0].cam_base;
   auto flush = [&]() {
     if (cur >= 0 && lane < 36) {
       // (a diagonal block is symmetric: the packed matrix, which keeps all of it, gets the words that carry the
@@ -1111,7 +1112,7 @@ __global__ __launch_bounds__(kBlock) void k_backsub(DevP P, LmParams lm, double*
   const WinState* st = P.ws + w;
   if (!st->active || st->solve_failed) return;
   if (d.kind == 0 && d.pad) return;  // a piece of a long landmark: k_long_point's
-  const WinDesc wd = win_desc(P, w);
+  const WinDesc wd = P.wd[w];
   const int sel = st->sel;
   const int t = threadIdx.x;
   const bool live = t < d.n_obs;
@@ -1239,7 +1240,7 @@ __global__ __launch_bounds__(kBlock) void k_long_point(DevP P, LmParams lm) {
   const WinState* st = P.ws + w;
   if (!st->active) return;
   if (PHASE == 2 && st->solve_failed) return;
-  const WinDesc wd = win_desc(P, w);
+  const WinDesc wd = P.wd[w];
   const int sel = st->sel;
   const int t = threadIdx.x, pp = L.pp;
   const double p[3] = {P.points[sel][3ll * pp], P.points[sel][3ll * pp + 1], P.points[sel][3ll * pp + 2]};
@@ -1387,7 +1388,7 @@ __global__ __launch_bounds__(kBlock) void k_long_point(DevP P, LmParams lm) {
 // workgroup (any size that is a multiple of 64; red: two words per wave)
 __device__ __forceinline__ void pose_update_window(const DevP& P, int w, double* red) {
   WinState* st = P.ws + w;
-  const WinDesc wd = win_desc(P, w);
+  const WinDesc wd = P.wd[w];
   const int sel = st->sel;
   double acc[2] = {0.0, 0.0};
   for (int c = wd.pose_begin + threadIdx.x; c < wd.pose_end; c += blockDim.x) {
@@ -1438,7 +1439,7 @@ constexpr int kWsum = 8;  // doubles of P.wsum per window
 __global__ __launch_bounds__(kBlock) void k_window_init(DevP P, LmParams lm, int mode, int zero_S) {
   __shared__ double red[3 * 4];
   const int w = blockIdx.x;
-  const WinDesc wd = win_desc(P, w);
+  const WinDesc wd = P.wd[w];
   WinState* st = P.ws + w;
   if (zero_S) {
     double2* Sw = reinterpret_cast<double2*>(P.S + wd.S_off);
@@ -1575,7 +1576,7 @@ __device__ __forceinline__ void window_control_body(const DevP& P, const LmParam
   const int w = blockIdx.x;
   WinState* st = P.ws + w;
   if (!st->active) return;
-  const WinDesc wd = win_desc(P, w);
+  const WinDesc wd = P.wd[w];
   const bool failed = st->solve_failed != 0;
   // acc: 0 model term, 1 point step^2, 2 point x^2, 3 candidate cost, 4 bad flag
   double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
@@ -1702,7 +1703,7 @@ __global__ __launch_bounds__(kWideBlock) void k_window_control(DevP P, LmParams 
   __syncthreads();  // the decision thread 0 has just written
   const WinState* st = P.ws + blockIdx.x;
   if (!*reinterpret_cast<const volatile int*>(&st->active)) return;
-  const WinDesc wd = win_desc(P, blockIdx.x);
+  const WinDesc wd = P.wd[blockIdx.x];
   double2* Sw = reinterpret_cast<double2*>(P.S + wd.S_off);
   const long long n2 = 18ll * ((long long)wd.ncam * (wd.ncam + 1) / 2);
   for (long long i = threadIdx.x; i < n2; i += blockDim.x) Sw[i] = make_double2(0.0, 0.0);
@@ -1828,7 +1829,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_window_solve_small(DevP P, Lm
   WinState* st = P.ws + w;
   if (!st->active) return;
   HIPBA_TICK(0);
-  const WinDesc wd = win_desc(P, w);
+  const WinDesc wd = P.wd[w];
   window_gradient_check(P, lm, wd, st, red, kFused);
   HIPBA_TICK(1);
   if (!st->active) return;
@@ -2044,7 +2045,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_window_solve_tiles(DevP P, Lm
   WinState* st = P.ws + w;
   if (!st->active) return;
   HIPBA_TICK(0);
-  const WinDesc wd = win_desc(P, w);
+  const WinDesc wd = P.wd[w];
   const int nb = wd.ncam;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const double* Sg = P.S + wd.S_off;
@@ -2314,7 +2315,7 @@ __global__ __launch_bounds__(kWideBlock) void k_window_gradient(DevP P, LmParams
   const int w = blockIdx.x;
   WinState* st = P.ws + w;
   if (!st->active) return;
-  window_gradient_check(P, lm, win_desc(P, w), st, red, mode);
+  window_gradient_check(P, lm, P.wd[w], st, red, mode);
 }
 
 // ------------------------------------------------------------------------------------------
