@@ -486,6 +486,18 @@ def main():
         # never will: it only waits for the child.
         sys.exit(launch_ranks(args.gpus))
 
+    # A rank that hangs (a collective that never completes) must not hold the job for ever: after 25 minutes the
+    # process says so and leaves.  (A default run takes well under two.)
+    import threading
+
+    def give_up():
+        print("bench.py: no result after 25 minutes, giving up", file=sys.stderr, flush=True)
+        os._exit(3)
+
+    watchdog = threading.Timer(1500.0, give_up)
+    watchdog.daemon = True
+    watchdog.start()
+
     import torch
     import torch.distributed as dist
     from stereo_visual_odometry_amd import hipba, scenes
@@ -521,6 +533,7 @@ def main():
         return hipba.default_options(max_num_iterations=iters, linear_solver=lin, pcg_max_iterations=2000,
                                      pcg_tolerance=1e-10)
 
+    native_comm = True
     if world > 1:
         from stereo_visual_odometry_amd.sharded import ShardedProblem, TorchComm
         if rehearsal:
@@ -530,7 +543,19 @@ def main():
             # engine on its stream, no Python in the loop; torch.distributed only carries the 128-byte id
             ids = [hipba.RcclComm.unique_id() if rank == 0 else None]
             dist.broadcast_object_list(ids, src=0)
-            comm = hipba.RcclComm(local_rank, ids[0], rank, world)
+            try:
+                comm = hipba.RcclComm(local_rank, ids[0], rank, world)
+                made = 1
+            except Exception as e:  # (no RCCL to load, or its initialisation refused)
+                print("bench.py: rank %d: native RCCL communicator failed (%r)" % (rank, e), file=sys.stderr)
+                comm, made = None, 0
+            agreed = torch.tensor([made], device="cuda")
+            dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+            if int(agreed.item()) == 0:
+                # every rank falls back together: the same sums through torch.distributed's RCCL process group, issued
+                # from the all-reduce callback on the engine's streams
+                comm = TorchComm(torch.device("cuda", local_rank))
+                native_comm = False
         job = ShardedProblem(solver, prob, comm)
         run = lambda iters: job.solve(lm_options(iters))
         reset = job.reset
@@ -600,7 +625,8 @@ def main():
             result["allreduce_calls_per_step"] = comm.calls / max(steps_done + args.warmup, 1)
             result["allreduce_bytes_per_step"] = comm.bytes / max(steps_done + args.warmup, 1)
             result["collective"] = ("gloo through torch.distributed, every rank on device 0 (rehearsal)" if rehearsal
-                                    else "ncclAllReduce (RCCL) issued by the engine on its own streams")
+                                    else "ncclAllReduce (RCCL) issued by the engine on its own streams" if native_comm
+                                    else "torch.distributed all_reduce (RCCL process group) from the engine's callback")
             result["collective_ranks"] = world
     if world > 1:
         dist.barrier()
