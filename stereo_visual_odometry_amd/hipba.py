@@ -33,10 +33,12 @@ _bp = C.POINTER(C.c_uint8)
 
 
 class CProblem(C.Structure):
+    # (the array members are declared as untyped addresses -- the layout is that of the header's typed pointers -- so that
+    # Problem.c() can store plain integers: seven typed ctypes casts per call were 20 us of a 1 ms window solve)
     _fields_ = [
-        ("n_poses", C.c_int32), ("poses", _dp), ("pose_const", _bp),
-        ("n_points", C.c_int32), ("points", _dp), ("point_const", _bp),
-        ("n_obs", C.c_int64), ("obs_pose", _ip), ("obs_point", _ip), ("obs_uv", _dp),
+        ("n_poses", C.c_int32), ("poses", C.c_void_p), ("pose_const", C.c_void_p),
+        ("n_points", C.c_int32), ("points", C.c_void_p), ("point_const", C.c_void_p),
+        ("n_obs", C.c_int64), ("obs_pose", C.c_void_p), ("obs_point", C.c_void_p), ("obs_uv", C.c_void_p),
         ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
         ("camera_model", C.c_int32),
     ]
@@ -250,20 +252,12 @@ class Problem:
                        self.camera_model, self.pose_const, self.point_const)
 
     def c(self):
-        p = CProblem()
-        p.n_poses = self.poses.shape[0]
-        p.poses = self.poses.ctypes.data_as(_dp)
-        p.pose_const = None if self.pose_const is None else self.pose_const.ctypes.data_as(_bp)
-        p.n_points = self.points.shape[0]
-        p.points = self.points.ctypes.data_as(_dp)
-        p.point_const = None if self.point_const is None else self.point_const.ctypes.data_as(_bp)
-        p.n_obs = self.obs_pose.shape[0]
-        p.obs_pose = self.obs_pose.ctypes.data_as(_ip)
-        p.obs_point = self.obs_point.ctypes.data_as(_ip)
-        p.obs_uv = self.obs_uv.ctypes.data_as(_dp)
-        p.fx, p.fy, p.cx, p.cy = self.K
-        p.camera_model = self.camera_model
-        return p
+        """The hipba_problem view of the arrays (which must stay alive, and where they are, while it is in use)."""
+        addr = lambda a: None if a is None else a.__array_interface__["data"][0]
+        return CProblem(self.poses.shape[0], addr(self.poses), addr(self.pose_const),
+                        self.points.shape[0], addr(self.points), addr(self.point_const),
+                        self.obs_pose.shape[0], addr(self.obs_pose), addr(self.obs_point), addr(self.obs_uv),
+                        self.K[0], self.K[1], self.K[2], self.K[3], self.camera_model)
 
 
 def _summary_dict(s, log=None):
