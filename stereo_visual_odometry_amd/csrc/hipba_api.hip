@@ -93,6 +93,23 @@ class HostWorkers {
     job_ = nullptr;
     return !failed_;
   }
+  // f(1) on a worker while the caller goes on; f must stay alive until wait() has returned, and no other job may be
+  // handed out in between.
+  void start(const std::function<void(int)>& f) {
+    failed_ = false;
+    if (threads_.empty()) threads_.emplace_back([this] { loop(1); });
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      job_ = &f; parts_ = 2; pending_ = 1; ++generation_;
+    }
+    go_.notify_all();
+  }
+  bool wait() {
+    std::unique_lock<std::mutex> lk(m_);
+    done_.wait(lk, [this] { return pending_ == 0; });
+    job_ = nullptr;
+    return !failed_;
+  }
 
  private:
   void call(const std::function<void(int)>& f, int i) {
@@ -482,6 +499,14 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
     }
   };
   bool side_lists_done = false;
+  std::atomic<bool> lists_claimed{false};
+  const std::function<void(int)> lists_job = [&](int) { if (!lists_claimed.exchange(true)) build_side_lists(); };
+  bool worker_busy = false;  // lists_job handed to a worker and not yet collected
+  // (collects it on every way out of this function: the job refers to this frame)
+  struct CollectWorker {
+    HostWorkers& w; bool& busy;
+    ~CollectWorker() { if (busy) (void)w.wait(); }
+  } collect_worker{h->workers, worker_busy};
   // ---- observations: PM | VC | CC --------------------------------------------------------------
   std::vector<long long> pp_start(n_pm_points + 1, 0);
   for (long long gp = 0; gp < NPT; ++gp)
@@ -498,8 +523,14 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   // observations frame by frame (the reference does: optimizer.cpp:37-51) hands over sorted segments, and the two
   // passes over the observations that sort the segments and look for repeats are then skipped.
   const bool dense_path = nw == 1 && 6 * max_ncam > kSmallMaxN;
+  // (what the placement touches per observation sits together: one cache line by landmark and one word by point instead
+  // of three and two)
+  struct SegState { long long cur, last_key; int nvar, pad; };
+  std::vector<SegState> seg(std::max(n_pm_points, 1));
+  for (int d = 0; d < n_pm_points; ++d) seg[d] = SegState{pp_start[d], std::numeric_limits<long long>::min(), 0, 0};
+  std::vector<int> where(NPT);  // device landmark index of a point; of a constant one, its complement (negative)
+  for (long long gp = 0; gp < NPT; ++gp) where[gp] = pt_c[gp] ? ~dp_of[gp] : dp_of[gp];
   std::vector<int> nvar(std::max(n_pm_points, 1), 0);
-  std::vector<long long> last_key(dense_path ? 0 : std::max(n_pm_points, 1), std::numeric_limits<long long>::min());
   bool seg_unsorted = false, seg_repeat = false;
   {
     // The landmarks can be cut into ranges, one per thread: every thread reads all observations and places those of its
@@ -509,7 +540,6 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
     // hand out and collect, and a part's time is its scan of ALL observations with a range test that the branch
     // predictor cannot learn (85 us each for three parts against 103 us for one thread doing everything) -- so a window
     // is placed by ONE thread with the lists beside it, and only inputs of a million observations are cut up.
-    std::vector<long long> cur(pp_start.begin(), pp_start.end() - 1);
     const int n_parts = n_all >= 1000000 ? 4 : 1;
     bool part_unsorted[4] = {false, false, false, false}, part_repeat[4] = {false, false, false, false};
     auto place = [&](int part) {
@@ -520,30 +550,32 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
         const hipba_problem& p = probs[w];
         const int pose_base = R->meta[w].pose_base;
         for (long long k = 0; k < p.n_obs; ++k) {
-          const long long gp = pt_base[w] + p.obs_point[k];
+          const int wh = where[pt_base[w] + p.obs_point[k]];
           long long dst;
-          int c;
-          if (!pt_c[gp]) {
-            const int d = dp_of[gp];
+          int c, d;
+          if (wh >= 0) {
+            d = wh;
             if (d < d_lo || d >= d_hi) continue;
             c = pose_base + p.obs_pose[k];
             const int g = pose_gslot[c];
-            dst = cur[d]++;
-            nvar[d] += g >= 0;
+            SegState& sg = seg[d];
+            dst = sg.cur++;
+            sg.nvar += g >= 0;
             if (!dense_path) {
               const long long key = ((long long)g << 32) + c;
-              if (key < last_key[d]) unsorted = true;
-              else if (key == last_key[d] && g >= 0) repeat = true;
-              last_key[d] = key;
+              if (key < sg.last_key) unsorted = true;
+              else if (key == sg.last_key && g >= 0) repeat = true;
+              sg.last_key = key;
             }
           } else {
             if (part != 0) continue;
+            d = ~wh;
             c = pose_base + p.obs_pose[k];
             if (!pose_c[c]) { dst = vc_cur++; vc_window_count[w]++; }
             else { dst = cc_cur++; cc_window_count[w]++; }
           }
           obs_pose[dst] = c;
-          obs_dp[dst] = dp_of[gp];
+          obs_dp[dst] = d;
           obs_uv[2 * dst] = p.obs_uv[2 * k];
           obs_uv[2 * dst + 1] = p.obs_uv[2 * k + 1];
         }
@@ -552,15 +584,25 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
     };
     const bool lists_here = !dense_path && n_slots > 0;  // (the large window's slots are not final yet)
     const int n_jobs = n_parts + (lists_here && n_all >= 12000 ? 1 : 0);
-    if (n_jobs == 1) {
+    if (n_parts == 1) {
+      // A window: the lists are offered to a worker and this thread places the observations meanwhile.  Whoever gets
+      // to the lists first builds them -- a worker that wakes late (a sleeping core) finds them taken and costs
+      // nothing, where waiting for it cost up to 0.2 ms now and then.
+      if (n_jobs > 1) { h->workers.start(lists_job); worker_busy = true; }
       place(0);
-      if (lists_here) { build_side_lists(); side_lists_done = true; }
+      if (lists_here) {
+        if (!lists_claimed.exchange(true)) build_side_lists();
+        else if (!h->workers.wait()) { worker_busy = false; return fail(HIPBA_ERR_OUT_OF_MEMORY, "host analysis of the camera-major lists ran out of memory"); }
+        else worker_busy = false;
+        side_lists_done = true;
+      }
     } else {
       if (!h->workers.run(n_jobs, [&](int i) { if (i < n_parts) place(i); else build_side_lists(); }))
         return fail(HIPBA_ERR_OUT_OF_MEMORY, "host analysis of the observations ran out of memory");
       side_lists_done = n_jobs > n_parts;
     }
     for (int i = 0; i < n_parts; ++i) { seg_unsorted |= part_unsorted[i]; seg_repeat |= part_repeat[i]; }
+    for (int d = 0; d < n_pm_points; ++d) nvar[d] = seg[d].nvar;
     for (int w = 0; w < nw; ++w) R->meta[w].n_act_obs = 0;
   }
 
@@ -937,6 +979,7 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
     if (n_thr <= 1) {
       group_range(0, 0, n_blk_pm);
     } else if (n_thr <= 8) {
+      if (worker_busy) { (void)h->workers.wait(); worker_busy = false; }
       // the handle's sleeping workers (and this thread) take the blocks
       if (!h->workers.run(n_thr, [&](int i) { group_range(i, lo(i), lo(i + 1)); }))
         return fail(HIPBA_ERR_OUT_OF_MEMORY, "host analysis of the pair lists ran out of memory");
