@@ -293,7 +293,9 @@ struct ArenaPlan {
 int ensure_arena(hipba_handle_s* h, size_t bytes) {
   if (h->arena_bytes >= bytes) return HIPBA_OK;
   if (h->arena) { HIPBA_HIP(hipFree(h->arena)); h->arena = nullptr; h->arena_bytes = 0; }
-  const size_t want = align_up(bytes + bytes / 4, 1 << 20);
+  // (never less than 16 MB: a sequence's first windows grow frame by frame, and every regrowth is a hipFree and a
+  // hipMalloc -- a few hundred microseconds -- in the middle of a 1 ms call; a keyframe window needs 3-4 MB)
+  const size_t want = std::max<size_t>(align_up(bytes + bytes / 4, 1 << 20), (size_t)16 << 20);
   HIPBA_HIP(hipMalloc(&h->arena, want));
   h->arena_bytes = want;
   return HIPBA_OK;
@@ -302,7 +304,7 @@ int ensure_arena(hipba_handle_s* h, size_t bytes) {
 int ensure_staging(hipba_handle_s* h, size_t bytes) {
   if (h->staging_bytes >= bytes) return HIPBA_OK;
   if (h->staging) { HIPBA_HIP(hipHostFree(h->staging)); h->staging = nullptr; h->staging_bytes = 0; }
-  const size_t want = align_up(bytes + bytes / 4, 1 << 20);
+  const size_t want = std::max<size_t>(align_up(bytes + bytes / 4, 1 << 20), (size_t)8 << 20);  // (as the arena: not below 8 MB)
   HIPBA_HIP(hipHostMalloc(&h->staging, want, hipHostMallocDefault));
   h->staging_bytes = want;
   return HIPBA_OK;
