@@ -1368,6 +1368,29 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
   // this side); the host reads the word the control kernel stores into the pinned ring, tagged with the pass number.
   const bool spin_poll = lag > 0 && P.n_windows == 1 && !timing;
   if (spin_poll) for (int i = 0; i < 4; ++i) h->h_count[i] = 0;  // (nothing of an earlier solve is in flight: each ends in a synchronize)
+  // the control kernel of pass `want` stores (pass << 1) | active straight into the ring: waits for that word and
+  // returns 1 (still active), 0 (stopped) or a negative error code
+  auto pass_word = [&](int want) -> int {
+    volatile int* word = h->h_count + (want & 3);
+    double deadline = 0.0;
+    for (long long spins = 0; (*word >> 1) != want; ++spins) {
+      __builtin_ia32_pause();
+      if ((spins & 0xfff) == 0xfff) {
+        const double now = now_s();
+        if (deadline == 0.0) deadline = now + 10.0;
+        else if (now > deadline) {
+          // ten seconds for a pass of a small window: something is wrong on the device; let the runtime say what
+          HIPBA_HIP(hipStreamSynchronize(s));
+          if ((*word >> 1) != want) return fail(HIPBA_ERR_INTERNAL, "pass %d of the solve never reported back", want);
+        }
+      }
+    }
+    return *word & 1;
+  };
+  // With one pass of lag the host does not queue a whole pass ahead but only its first launch (the linearisation,
+  // the longest one but the solve): the word of the pass before is there by the time that launch has been queued, and
+  // the rest of the pass follows while it runs.  A window that has stopped then costs one idle launch, not four.
+  const bool split_pass = spin_poll && lag == 1;
   for (int iter = 1; iter <= std::max(lm.max_num_iterations, 0); ++iter) {
     PHASE(0);
     // S is zeroed first so that, unsharded, the camera-block launch can initialise the reduced system too
@@ -1419,6 +1442,11 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
         }
       }
     }
+    if (split_pass && iter >= 2) {
+      const int still = pass_word(iter - 1);
+      if (still < 0) return still;
+      if (still == 0) break;
+    }
     if (small && !sharded) {
       HIPBA_HIP(launch_window_solve_small(P, lm, max_n, 1, iter == 1 ? 1 : 2, s));  // also forms the candidate poses
     } else {
@@ -1460,26 +1488,12 @@ int run_lm(hipba_handle_s* h, hipba_device_problem_s* R, const hipba_options& o,
     // copy is queued behind them)
     if (sharded || P.n_windows != 1) HIPBA_HIP(launch_count_active(P, h->h_count + slot, s));
     if (!spin_poll) HIPBA_HIP(hipEventRecord(h->poll_ev[slot], s));
-    if (iter - lag >= 1) {
+    if (iter - lag >= 1 && !split_pass) {
       const int seen = (iter - lag) & 3;
       if (spin_poll) {
-        // the control kernel of pass iter - lag stores (pass << 1) | active straight into the ring: wait for that word
-        volatile int* word = h->h_count + seen;
-        const int want = iter - lag;
-        double deadline = 0.0;
-        for (long long spins = 0; (*word >> 1) != want; ++spins) {
-          __builtin_ia32_pause();
-          if ((spins & 0xfff) == 0xfff) {
-            const double now = now_s();
-            if (deadline == 0.0) deadline = now + 10.0;
-            else if (now > deadline) {
-              // ten seconds for a pass of a small window: something is wrong on the device; let the runtime say what
-              HIPBA_HIP(hipStreamSynchronize(s));
-              if ((*word >> 1) != want) return fail(HIPBA_ERR_INTERNAL, "pass %d of the solve never reported back", want);
-            }
-          }
-        }
-        if ((*word & 1) == 0) break;
+        const int still = pass_word(iter - lag);
+        if (still < 0) return still;
+        if (still == 0) break;
       } else {
         HIPBA_HIP(hipEventSynchronize(h->poll_ev[seen]));
         if (timing) { const int rc = collect(iter - lag); if (rc) return rc; }
