@@ -2184,11 +2184,16 @@ __global__ __launch_bounds__(kSolveThreads) void k_window_solve_tiles(DevP P, Lm
     HIPBA_LAP(0);
     __syncthreads();
     HIPBA_LAP(1);
-    // trailing tiles: A(i2,j2) -= L(i2,j) L(j2,j)^T.  Wave 0 takes the next diagonal tile alone and factors it at
-    // once (the longest single-wave job of a step) while the other waves share the remaining tiles.
+    // Updates, LEFT-looking: in step j the tiles of column j + 1 below the diagonal receive the products of ALL columns
+    // 0 .. j at once (one accumulator chain per tile, the tile read and written once), and the diagonal tile j + 2
+    // those of columns 0 .. j as well, so that wave 0 finds it lacking only column j + 1 a step later.  Applied
+    // right-looking -- column j to the whole trailing block at once -- the same 220 products of a 30-keyframe window came
+    // 54 in the first step and one in the last, and the first steps waited for the updating waves; this way a step has
+    // at most 30, and the longest job of every step is wave 0's: the next diagonal tile, updated with column j and
+    // factored at once, at raised priority.  Wave 4 shares wave 0's SIMD -- and with it the fp64 pipe, which vector and
+    // matrix-core instructions both use: it takes no tiles, only the forward substitution's chain.
     if (wave == 0) {
       if (j + 1 < nt) {
-        // (raised priority: the wave shares its SIMD with one of the updating waves, and this is the step's longest job)
         __builtin_amdgcn_s_setprio(3);
         double* C = Lt + ltile(j + 1, j + 1);
         v4d acc = tile_load_t(C, lane);
@@ -2200,54 +2205,41 @@ __global__ __launch_bounds__(kSolveThreads) void k_window_solve_tiles(DevP P, Lm
         if (!tile_cholesky_inverse(C, nullptr, 0, lane) && lane == 0) fail = 1;
         __builtin_amdgcn_s_setprio(0);
       }
-      // (steps with a large trailing block leave this wave waiting: it takes the forward chain there; in the others
-      // the wave without tiles does)
-      if ((nt - j - 1) * (nt - j) / 2 - 1 >= 30) forward_chain(j);
+    } else if (wave == 4) {
+      forward_chain(j);
     } else {
-      // this wave's tiles of the trailing block: every seventh of the row-by-row list (row i2 holds j2 = j + 1 .. i2),
-      // walked directly -- scanning the whole list with a modulo test per tile cost as much as the products -- and two
-      // at a time: all operands of both tiles are requested before the first product, and the two accumulator chains
-      // alternate on the matrix core.
-      // Wave 4 shares a SIMD -- and with it the fp64 pipe, which vector and matrix-core instructions both use -- with
-      // wave 0, whose chain through the diagonal tile is the longest job of a step unless the trailing block is large:
-      // it takes tiles only then (the first steps of a 30-keyframe window).
-      const int n_trailing = (nt - j - 1) * (nt - j) / 2 - 1;
-      const bool seven = n_trailing >= 30;
-      if (wave == 4 && !seven) forward_chain(j);
-      const int kUpd = seven ? kSolveThreads / 64 - 1 : kSolveThreads / 64 - 2;
-      const int widx = (seven || wave < 4) ? wave - 1 : wave - 2;  // this wave's place among the updating ones
-      if (j > 0 && (seven || wave != 4)) forward_rows(j, widx, kUpd);
-      int i2 = (wave == 4 && !seven) ? nt : j + 2, j2 = j + 1 + widx;
-      while (i2 < nt && j2 > i2) { j2 -= i2 - j; ++i2; }
-      while (i2 < nt) {
-        double* C0 = Lt + ltile(i2, j2);
-        const double* M0 = Lt + ltile(j2, j);
-        const double* N0 = Lt + ltile(i2, j);
-        j2 += kUpd;
-        while (i2 < nt && j2 > i2) { j2 -= i2 - j; ++i2; }
-        const bool two = i2 < nt;
-        double* C1 = two ? Lt + ltile(i2, j2) : C0;
-        const double* M1 = two ? Lt + ltile(j2, j) : M0;
-        const double* N1 = two ? Lt + ltile(i2, j) : N0;
-        if (two) {
-          j2 += kUpd;
-          while (i2 < nt && j2 > i2) { j2 -= i2 - j; ++i2; }
-        }
-        double a0[4], b0[4], a1[4], b1[4];
-        v4d acc0 = tile_load_t(C0, lane), acc1 = tile_load_t(C1, lane);
+      constexpr int kUpd = kSolveThreads / 64 - 2;
+      const int widx = wave < 4 ? wave - 1 : wave - 2;  // this wave's place among the updating ones
+      if (j > 0) forward_rows(j, widx, kUpd);
+      const int n_col = nt - j - 2 > 0 ? nt - j - 2 : 0;       // tiles (j + 2 .. nt - 1, j + 1)
+      const int n_jobs = n_col + (j + 2 < nt ? 1 : 0);          // and the diagonal tile (j + 2, j + 2)
+      // (the jobs of a step are as long as the step's number: the first one goes to a different wave every step)
+      for (int idx = (widx + kUpd - j % kUpd) % kUpd; idx < n_jobs; idx += kUpd) {
+        const bool dg = idx == n_col;
+        const int r = dg ? j + 2 : j + 2 + idx, c = dg ? j + 2 : j + 1;
+        double* C = Lt + ltile(r, c);
+        v4d acc = tile_load_t(C, lane);
+        // the operands of column k + 1 are requested before the products of column k are issued
+        double a[4], b[4];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
           const int o = (kk * 4 + (lane >> 4)) * TB + (lane & 15);
-          a0[kk] = -M0[o]; b0[kk] = N0[o];
-          a1[kk] = -M1[o]; b1[kk] = N1[o];
+          a[kk] = -Lt[ltile(c, 0) + o]; b[kk] = Lt[ltile(r, 0) + o];
         }
+        for (int k = 0; k <= j; ++k) {
+          double an[4], bn[4];
+          const int kn = k < j ? k + 1 : k;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[kk], b0[kk], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kk], b1[kk], acc1, 0, 0, 0);
+          for (int kk = 0; kk < 4; ++kk) {
+            const int o = (kk * 4 + (lane >> 4)) * TB + (lane & 15);
+            an[kk] = -Lt[ltile(c, kn) + o]; bn[kk] = Lt[ltile(r, kn) + o];
+          }
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], b[kk], acc, 0, 0, 0);
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) { a[kk] = an[kk]; b[kk] = bn[kk]; }
         }
-        tile_store_t(C0, acc0, lane);
-        if (two) tile_store_t(C1, acc1, lane);
+        tile_store_t(C, acc, lane);
       }
     }
     HIPBA_LAP(2);
