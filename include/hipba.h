@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 /* bumped whenever a struct of this header changes size or layout; hipba_version() returns the library's value */
-#define HIPBA_VERSION 103
+#define HIPBA_VERSION 104
 
 /* status codes */
 enum {
@@ -334,23 +334,31 @@ int hipba_refine_pose(hipba_handle h, double fx, double fy, double cx, double cy
 
 /*
  * The whole of cv::solvePnPRansac(points_3d, points_2d, K, coeffs, rvec, tvec, false, iterations, reprojection_error,
- * confidence, inliers) as the reference calls it (src/solve/estimator.cpp:28-29: 1000 iterations, 3.0 px, 0.99), with
- * two differences that the GPU makes natural.  Minimal samples (four matches) are solved by Gauss-Newton from a prior
- * instead of in closed form, so the call takes one: pose, in = a pose near the answer (frame_prev_->pose_: the frames
- * of a sequence are a fraction of a metre apart), out = the result, camera-to-world as estimator.cpp:58-59 has it.
- * And every one of the `iterations` hypotheses is evaluated, all at once, instead of stopping by a confidence bound.
- * The hypothesis with the most matches inside reprojection_error wins (the lowest number among equals), `inliers`
- * ([n] bytes, may be NULL) marks them, *n_inliers counts them; with refine != 0 the pose is then refined on them
+ * confidence, inliers) as the reference calls it (src/solve/estimator.cpp:28-29: no extrinsic guess, 1000 iterations,
+ * 3.0 px, 0.99).  pose: out = the result, camera-to-world as estimator.cpp:58-59 has it; in = either a quaternion of
+ * four zeros -- no prior, as in the reference: every minimal sample (four matches) is solved in closed form, the
+ * perspective-three-point problem on its first three matches with the fourth choosing among the up to four
+ * solutions, and polished by Gauss-Newton on all four -- or a pose near the answer (frame_prev_->pose_: the frames of
+ * a sequence are a fraction of a metre apart), from which the samples are then fitted by Gauss-Newton alone.
+ * All `iterations` hypotheses are evaluated at once; the answer is the one OpenCV's sequential loop would end with
+ * on the same hypotheses: they are taken in the order of their numbers, one with more matches inside
+ * reprojection_error than every earlier one (and at least four) becomes the best and shrinks the number of
+ * iterations still to run to log(1 - confidence) / log(1 - (inlier share)^4) (cv::RANSACUpdateNumIters), and
+ * hypotheses past that bound do not count.  confidence in [0, 1]; 1 keeps (in practice) every hypothesis in play.
+ * *iterations_run (may be NULL) = that bound at the end, what the loop would have run.  `inliers` ([n] bytes, may be
+ * NULL) marks the winner's matches, *n_inliers counts them; with refine != 0 the pose is then refined on them
  * (hipba_refine_pose).  The sampling is a counter-based generator: the same seed gives the same hypotheses on any
  * machine.  A match counts as an inlier when its squared reprojection error is <= reprojection_error^2 (OpenCV's
  * test).  When no hypothesis gathers at least four inliers, or the winner is not finite, the call does what
  * cv::solvePnPRansac does when it returns false: pose is left as it came in, the mask is cleared and *n_inliers = 0
- * (the status is still HIPBA_OK: test *n_inliers).  Not result-identical to OpenCV: other samples, another minimal
- * solver, no early stop.  HIPBA_ERR_INVALID_ARGUMENT with fewer than 4 matches.
+ * (the status is still HIPBA_OK: test *n_inliers).  Not result-identical to OpenCV: other random samples, and
+ * OpenCV's minimal solver for five and more matches is EPnP on five of them.  HIPBA_ERR_INVALID_ARGUMENT with fewer
+ * than 4 matches or a confidence outside [0, 1].
  */
 int hipba_pnp_ransac(hipba_handle h, double fx, double fy, double cx, double cy, int32_t camera_model, int64_t n,
                      const double* points, const double* uv, double pose[7], int32_t iterations,
-                     double reprojection_error, uint64_t seed, int32_t refine, uint8_t* inliers, int64_t* n_inliers);
+                     double reprojection_error, double confidence, uint64_t seed, int32_t refine, uint8_t* inliers,
+                     int64_t* n_inliers, int32_t* iterations_run);
 
 /* ---- native RCCL communicator for sharded solves ------------------------------------------ */
 /*

@@ -5,8 +5,10 @@ cpu_baseline leg of bench.py -- never by the product package.  PARITY UNPINNED:
 see the header of ba_oracle.h.
 """
 import ctypes as C
+import math
 import os
 import subprocess
+import sys
 
 import numpy as np
 
@@ -272,18 +274,179 @@ def _splitmix64(state):
     return state, z ^ (z >> 31)
 
 
-def pnp_ransac(K, points, uv, prior, iterations=1000, reprojection_error=3.0, seed=0, camera_model=Z_FORWARD):
+def _cubic_largest_root(a2, a1, a0):
+    """Largest real root of z^3 + a2 z^2 + a1 z + a0 (trigonometric form / Cardano), two Newton steps."""
+    Q = (a2 * a2 - 3.0 * a1) / 9.0
+    R = (2.0 * a2 ** 3 - 9.0 * a2 * a1 + 27.0 * a0) / 54.0
+    Q3 = Q ** 3
+    if R * R < Q3:
+        th = math.acos(min(max(R / math.sqrt(Q3), -1.0), 1.0))
+        m = -2.0 * math.sqrt(Q)
+        z = max(m * math.cos(th / 3.0), m * math.cos((th + 2.0 * math.pi) / 3.0),
+                m * math.cos((th - 2.0 * math.pi) / 3.0)) - a2 / 3.0
+    else:
+        A = -math.copysign((abs(R) + math.sqrt(max(R * R - Q3, 0.0))) ** (1.0 / 3.0), R)
+        B = Q / A if A != 0.0 else 0.0
+        z = A + B - a2 / 3.0
+    for _ in range(2):
+        f = ((z + a2) * z + a1) * z + a0
+        df = (3.0 * z + 2.0 * a2) * z + a1
+        if df != 0.0 and math.isfinite(f / df):
+            z -= f / df
+    return z
+
+
+def _quartic_real_roots(c4, c3, c2, c1, c0):
+    """Real roots of a quartic by Ferrari's method (resolvent cubic, two quadratics), three Newton steps each."""
+    if c4 == 0.0:
+        return []
+    b, c, d, e = c3 / c4, c2 / c4, c1 / c4, c0 / c4
+    if not all(math.isfinite(x) for x in (b, c, d, e)):
+        return []
+    p = c - 0.375 * b * b
+    q = d - 0.5 * b * c + 0.125 * b ** 3
+    r = e - 0.25 * b * d + 0.0625 * b * b * c - 0.01171875 * b ** 4
+    ys = []
+    z = _cubic_largest_root(2.0 * p, p * p - 4.0 * r, -q * q)
+    if not z > 1e-12 * (1.0 + abs(p)):
+        disc = p * p - 4.0 * r
+        if -1e-12 * (p * p + abs(4.0 * r)) < disc < 0.0:
+            disc = 0.0
+        if disc >= 0.0:
+            for w in (0.5 * (-p + math.sqrt(disc)), 0.5 * (-p - math.sqrt(disc))):
+                if w >= 0.0:
+                    ys += [math.sqrt(w), -math.sqrt(w)]
+    else:
+        sq = math.sqrt(z)
+        t1, t2 = 0.5 * (p + z - q / sq), 0.5 * (p + z + q / sq)
+        d1, d2 = z - 4.0 * t1, z - 4.0 * t2
+        if -1e-12 * (z + abs(4.0 * t1)) < d1 < 0.0:
+            d1 = 0.0
+        if -1e-12 * (z + abs(4.0 * t2)) < d2 < 0.0:
+            d2 = 0.0
+        if d1 >= 0.0:
+            ys += [0.5 * (-sq + math.sqrt(d1)), 0.5 * (-sq - math.sqrt(d1))]
+        if d2 >= 0.0:
+            ys += [0.5 * (sq + math.sqrt(d2)), 0.5 * (sq - math.sqrt(d2))]
+    out = []
+    for y in ys:
+        v = y - 0.25 * b
+        for _ in range(3):
+            f = (((v + b) * v + c) * v + d) * v + e
+            df = ((4.0 * v + 3.0 * b) * v + 2.0 * c) * v + d
+            if df != 0.0 and math.isfinite(f / df):
+                v -= f / df
+        if math.isfinite(v):
+            out.append(v)
+    return out
+
+
+def _triad(A, B, Cc):
+    d1, d2 = B - A, Cc - A
+    e3 = np.cross(d1, d2)
+    n1, n2, n3 = np.linalg.norm(d1), np.linalg.norm(d2), np.linalg.norm(e3)
+    if not n1 > 0.0 or not n3 > 1e-12 * n1 * n2:
+        return None
+    e1, e3 = d1 / n1, e3 / n3
+    return np.stack([e1, np.cross(e3, e1), e3])
+
+
+def _quat_of_rotation(M):
+    tr = M[0, 0] + M[1, 1] + M[2, 2]
+    if tr > 0.0:
+        s = 2.0 * math.sqrt(1.0 + tr)
+        return np.array([(M[2, 1] - M[1, 2]) / s, (M[0, 2] - M[2, 0]) / s, (M[1, 0] - M[0, 1]) / s, 0.25 * s])
+    if M[0, 0] > M[1, 1] and M[0, 0] > M[2, 2]:
+        s = 2.0 * math.sqrt(1.0 + M[0, 0] - M[1, 1] - M[2, 2])
+        return np.array([0.25 * s, (M[0, 1] + M[1, 0]) / s, (M[0, 2] + M[2, 0]) / s, (M[2, 1] - M[1, 2]) / s])
+    if M[1, 1] > M[2, 2]:
+        s = 2.0 * math.sqrt(1.0 + M[1, 1] - M[0, 0] - M[2, 2])
+        return np.array([(M[0, 1] + M[1, 0]) / s, 0.25 * s, (M[1, 2] + M[2, 1]) / s, (M[0, 2] - M[2, 0]) / s])
+    s = 2.0 * math.sqrt(1.0 + M[2, 2] - M[0, 0] - M[1, 1])
+    return np.array([(M[0, 2] + M[2, 0]) / s, (M[1, 2] + M[2, 1]) / s, 0.25 * s, (M[1, 0] - M[0, 1]) / s])
+
+
+def p3p_poses(K, P, uv, camera_model=Z_FORWARD):
+    """Camera-to-world poses (qx qy qz qw tx ty tz) that put three world points P [3, 3] on the pixels uv [3, 2]:
+    Grunert's perspective-three-point solution (quartic in the ratio of two of the points' distances; coefficients as
+    in Haralick et al., IJCV 1994), one pose per real root with positive distances, from the rigid motion between the
+    two triangles.  cv::solvePnPRansac (estimator.cpp:28-29) solves its minimal samples in closed form; OpenCV is
+    absent here, PARITY UNPINNED."""
+    fx, fy, cx, cy = K
+    f = []
+    for k in range(3):
+        x, y = (uv[k][0] - cx) / fx, (uv[k][1] - cy) / fy
+        n = 1.0 / math.sqrt(1.0 + x * x + y * y)
+        f.append(np.array([x * n, y * n, n]) if camera_model == Z_FORWARD else np.array([n, -x * n, -y * n]))
+    P = np.asarray(P, dtype=np.float64)
+    Ep = _triad(P[0], P[1], P[2])
+    if Ep is None:
+        return []
+    a2, b2, c2 = ((P[1] - P[2]) ** 2).sum(), ((P[0] - P[2]) ** 2).sum(), ((P[0] - P[1]) ** 2).sum()
+    ca, cb, cg = f[1] @ f[2], f[0] @ f[2], f[0] @ f[1]
+    k, m, ab, cr = (a2 - c2) / b2, (a2 + c2) / b2, a2 / b2, c2 / b2
+    A4 = (k - 1.0) ** 2 - 4.0 * cr * ca * ca
+    A3 = 4.0 * (k * (1.0 - k) * cb - (1.0 - m) * ca * cg + 2.0 * cr * ca * ca * cb)
+    A2 = 2.0 * (k * k - 1.0 + 2.0 * k * k * cb * cb + 2.0 * (1.0 - cr) * ca * ca - 4.0 * m * ca * cb * cg
+                + 2.0 * (1.0 - ab) * cg * cg)
+    A1 = 4.0 * (-k * (1.0 + k) * cb + 2.0 * ab * cg * cg * cb - (1.0 - m) * ca * cg)
+    A0 = (1.0 + k) ** 2 - 4.0 * ab * cg * cg
+    out = []
+    with np.errstate(all="ignore"):
+        for v in _quartic_real_roots(A4, A3, A2, A1, A0):
+            if not v > 0.0:
+                continue
+            den_u = 2.0 * (cg - v * ca)
+            if den_u == 0.0:
+                continue
+            u = ((k - 1.0) * v * v - 2.0 * k * cb * v + 1.0 + k) / den_u
+            den = 1.0 + v * v - 2.0 * v * cb
+            if not u > 0.0 or not math.isfinite(u) or not den > 0.0:
+                continue
+            s1 = math.sqrt(b2 / den)
+            Q = np.stack([s1 * f[0], u * s1 * f[1], v * s1 * f[2]])
+            Eq = _triad(Q[0], Q[1], Q[2])
+            if Eq is None:
+                continue
+            M = Ep.T @ Eq
+            pose = np.concatenate([_quat_of_rotation(M), P[0] - M @ Q[0]])
+            if np.isfinite(pose).all():
+                out.append(pose)
+    return out
+
+
+def ransac_update_iterations(p, ep, model_points, max_iters):
+    """cv::RANSACUpdateNumIters (OpenCV modules/calib3d/src/ptsetreg.cpp), restated."""
+    p = min(max(p, 0.0), 1.0)
+    ep = min(max(ep, 0.0), 1.0)
+    num = max(1.0 - p, sys.float_info.min)
+    denom = 1.0 - (1.0 - ep) ** model_points
+    if denom < sys.float_info.min:
+        return 0
+    num, denom = math.log(num), math.log(denom)
+    if denom >= 0.0 or -num >= max_iters * (-denom):
+        return max_iters
+    return int(round(num / denom))  # (Python rounds halves to even, as cvRound does)
+
+
+def pnp_ransac(K, points, uv, prior=None, iterations=1000, reprojection_error=3.0, seed=0, camera_model=Z_FORWARD,
+               confidence=1.0):
     """PnP by random sample consensus the way the engine's hipba_pnp_ransac states it (estimator.cpp:28-29 calls
     cv::solvePnPRansac; OpenCV is absent, PARITY UNPINNED): per hypothesis four matches from a splitmix64 stream seeded
-    by (seed, hypothesis number), at most ten Gauss-Newton steps on their reprojection error from `prior` (normal
-    equations with a 1e-9 relative damping, solved exactly), then the count of matches within the threshold; the
-    hypothesis with the most wins, the lowest number among equals.  Returns (pose before any refinement, mask, counts).
+    by (seed, hypothesis number); the start of the fit is `prior`, or with prior=None the closed-form pose of the first
+    three matches that reprojects the fourth best (p3p_poses; a sample without one counts no inliers); at most ten
+    Gauss-Newton steps on the four matches' reprojection error from there (normal equations with a 1e-9 relative
+    damping, solved exactly), then the count of matches within the threshold.  The hypotheses are then walked in
+    order as OpenCV's loop walks them: a count above every earlier one (and above 3) becomes the best and shrinks the
+    iterations to run (ransac_update_iterations); hypotheses past that bound do not count.
+    Returns (pose before any refinement, mask, counts, iterations the loop runs; pose None when nothing reaches 4).
     Python loops over the hypotheses: for the small cases of tests."""
     pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
     px = np.ascontiguousarray(uv, dtype=np.float64).reshape(-1, 2)
     n = pts.shape[0]
     thr2 = reprojection_error * reprojection_error
-    everything = Problem(np.asarray(prior, dtype=np.float64).reshape(1, 7), pts, np.zeros(n, dtype=np.int32),
+    ident = np.array([0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0])
+    everything = Problem(ident.reshape(1, 7).copy(), pts, np.zeros(n, dtype=np.int32),
                          np.arange(n, dtype=np.int32), px, K, camera_model, None, np.ones(n, dtype=np.uint8))
     counts = np.zeros(iterations, dtype=np.int64)
     poses = np.zeros((iterations, 7))
@@ -298,7 +461,20 @@ def pnp_ransac(K, points, uv, prior, iterations=1000, reprojection_error=3.0, se
                     break
             idx.append(cand)
         ii = np.array(idx)
-        pose = np.asarray(prior, dtype=np.float64).reshape(7).copy()
+        if prior is None:
+            best_err, pose = None, None
+            for cand_pose in p3p_poses(K, pts[ii[:3]], px[ii[:3]], camera_model):
+                one = Problem(cand_pose.reshape(1, 7), pts[ii[3:]], np.zeros(1, dtype=np.int32), np.zeros(1, dtype=np.int32),
+                              px[ii[3:]], K, camera_model, None, np.ones(1, dtype=np.uint8))
+                r4 = evaluate(one, JAC_ANALYTIC, apply_loss=False)["residuals"].reshape(2)
+                err = float(r4 @ r4)
+                if err == err and (best_err is None or err < best_err):
+                    best_err, pose = err, cand_pose.copy()
+            if pose is None:
+                poses[h] = ident
+                continue
+        else:
+            pose = np.asarray(prior, dtype=np.float64).reshape(7).copy()
         for _ in range(10):
             mini = Problem(pose.reshape(1, 7), pts[ii], np.zeros(4, dtype=np.int32), np.arange(4, dtype=np.int32), px[ii], K,
                            camera_model, None, np.ones(4, dtype=np.uint8))
@@ -321,7 +497,14 @@ def pnp_ransac(K, points, uv, prior, iterations=1000, reprojection_error=3.0, se
         res = evaluate(everything, JAC_ANALYTIC, apply_loss=False)["residuals"]
         counts[h] = int(((res * res).sum(axis=1) <= thr2).sum())
         poses[h] = pose
-    best = int(np.argmax(counts))  # the first of equals
+    best, best_count, limit, h = -1, 3, iterations, 0
+    while h < limit:
+        if counts[h] > best_count:
+            best, best_count = h, int(counts[h])
+            limit = ransac_update_iterations(confidence, (n - best_count) / n, 4, limit)
+        h += 1
+    if best < 0:
+        return None, np.zeros(n, dtype=np.uint8), counts, limit
     everything.poses[0] = poses[best]
     res = evaluate(everything, JAC_ANALYTIC, apply_loss=False)["residuals"]
-    return poses[best].copy(), ((res * res).sum(axis=1) <= thr2).astype(np.uint8), counts
+    return poses[best].copy(), ((res * res).sum(axis=1) <= thr2).astype(np.uint8), counts, limit

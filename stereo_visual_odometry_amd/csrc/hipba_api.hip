@@ -2168,9 +2168,11 @@ int hipba_refine_pose(hipba_handle h, double fx, double fy, double cx, double cy
 
 int hipba_pnp_ransac(hipba_handle h, double fx, double fy, double cx, double cy, int32_t camera_model, int64_t n,
                      const double* points, const double* uv, double pose[7], int32_t iterations,
-                     double reprojection_error, uint64_t seed, int32_t refine, uint8_t* inliers, int64_t* n_inliers) {
+                     double reprojection_error, double confidence, uint64_t seed, int32_t refine, uint8_t* inliers,
+                     int64_t* n_inliers, int32_t* iterations_run) {
   return guarded([&]() -> int {
     if (!h || !pose || !points || !uv) return fail(HIPBA_ERR_INVALID_ARGUMENT, "null argument");
+    if (!(confidence >= 0.0 && confidence <= 1.0)) return fail(HIPBA_ERR_INVALID_ARGUMENT, "confidence must lie in [0, 1]");
     if (n < 4) return fail(HIPBA_ERR_INVALID_ARGUMENT, "PnP by sample consensus needs at least 4 matches (got %lld)", (long long)n);
     if (iterations <= 0 || iterations > (1 << 20)) return fail(HIPBA_ERR_INVALID_ARGUMENT, "iterations out of range (%d)", iterations);
     if (!(reprojection_error > 0.0)) return fail(HIPBA_ERR_INVALID_ARGUMENT, "reprojection_error must be positive");
@@ -2203,12 +2205,15 @@ int hipba_pnp_ransac(hipba_handle h, double fx, double fy, double cx, double cy,
     double* d_out = reinterpret_cast<double*>(dv + up_al + count_bytes + poses_bytes);
     unsigned char* d_mask = reinterpret_cast<unsigned char*>(dv + up_al + count_bytes + poses_bytes + 256);
     const CameraK K{fx, fy, cx, cy, camera_model};
-    HIPBA_HIP(launch_pnp_ransac(K, n, d_pts, d_uv, d_prior, iterations, seed, reprojection_error, d_count, d_poses, d_out,
-                                d_mask, s));
+    // a quaternion of zeros is no rotation: the caller has no prior, the minimal samples are solved in closed form
+    const int closed_form = pose[0] == 0.0 && pose[1] == 0.0 && pose[2] == 0.0 && pose[3] == 0.0;
+    HIPBA_HIP(launch_pnp_ransac(K, n, d_pts, d_uv, d_prior, closed_form, iterations, seed, reprojection_error, confidence,
+                                d_count, d_poses, d_out, d_mask, s));
     // result and mask come back in one copy (they are adjacent in the work area)
     HIPBA_HIP(hipMemcpyAsync(st, d_out, 256 + (size_t)n, hipMemcpyDeviceToHost, s));
     HIPBA_HIP(hipStreamSynchronize(s));
     const long long best = (long long)st[7];
+    if (iterations_run) *iterations_run = (int32_t)st[8];
     bool finite = true;
     for (int i = 0; i < 7; ++i) finite = finite && std::isfinite(st[i]);
     if (best < 4 || !finite) {

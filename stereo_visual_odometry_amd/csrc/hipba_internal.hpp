@@ -50,8 +50,9 @@ hipError_t launch_se3_plus(long long n, const double* d_poses, const double* d_d
 // PnP hypotheses by random sample consensus: n_hyp poses from four-match samples (Gauss-Newton from d_prior), their inlier
 // counts, then d_out = the best pose [7] + its count [1] and d_mask [n]; every pointer is device memory
 hipError_t launch_pnp_ransac(const CameraK& K, long long n, const double* d_pts, const double* d_uv, const double* d_prior,
-                             int n_hyp, unsigned long long seed, double reprojection_error, int* d_count, double* d_poses,
-                             double* d_out, unsigned char* d_mask, hipStream_t s);
+                             int closed_form, int n_hyp, unsigned long long seed, double reprojection_error,
+                             double confidence, int* d_count, double* d_poses, double* d_out, unsigned char* d_mask,
+                             hipStream_t s);
 
 // ---- reduced-system solvers for one large window (dense_solver.hip) ----------------------------
 struct BigWork {

@@ -7,8 +7,11 @@
 // One lane per match here; the three steps never leave registers.
 #include <hip/hip_runtime.h>
 
+#include <cfloat>
+
 #include "ba_math.hpp"
 #include "hipba_internal.hpp"
+#include "p3p.hpp"
 
 namespace hipba {
 
@@ -149,11 +152,13 @@ hipError_t launch_se3_plus(long long n, const double* d_poses, const double* d_d
 
 // ---- PnP by random sample consensus (src/solve/estimator.cpp:28-29: cv::solvePnPRansac) -----------------------------
 // One lane per hypothesis: four matches drawn with a counter-based generator (the same draw for the same seed and
-// hypothesis number wherever it runs), the pose that fits them by Gauss-Newton on the reprojection error from the
-// caller's prior (consecutive frames of a sequence: the prior is the previous frame's pose), then the number of matches
-// the pose reprojects within the threshold.  A second launch picks the hypothesis with the most (the lowest number
-// among equals) and marks its inliers.  OpenCV solves its minimal samples in closed form and stops early by a
-// confidence bound; here every hypothesis is evaluated, all at once.
+// hypothesis number wherever it runs); the pose of the first three in closed form (p3p.hpp), the fourth choosing among
+// its up to four solutions -- or, when the caller has a prior (consecutive frames of a sequence: the previous frame's
+// pose), that prior --; Gauss-Newton on the four matches' reprojection error from there; then the number of matches
+// the pose reprojects within the threshold.  A second launch walks the hypotheses in the order of their numbers the
+// way OpenCV's sequential loop does (a better one shrinks the number of iterations still to run by the confidence
+// bound, hypotheses past the bound do not count), takes the best (the lowest number among equals) and marks its
+// inliers.  Every hypothesis is evaluated, all at once; the bound only decides which of them the answer may come from.
 __host__ __device__ __forceinline__ unsigned long long splitmix64(unsigned long long& state) {
   unsigned long long z = (state += 0x9E3779B97F4A7C15ull);
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -166,8 +171,8 @@ constexpr int kPnpGaussNewton = 10;
 
 __global__ __launch_bounds__(64) void k_pnp_hypotheses(CameraK K, long long n, const double* __restrict__ pts,
                                                        const double* __restrict__ uv, const double* __restrict__ prior,
-                                                       int n_hyp, unsigned long long seed, double thr2, int* __restrict__ count,
-                                                       double* __restrict__ poses) {
+                                                       int closed_form, int n_hyp, unsigned long long seed, double thr2,
+                                                       int* __restrict__ count, double* __restrict__ poses) {
   const int h = blockIdx.x * blockDim.x + threadIdx.x;
   if (h >= n_hyp) return;
   unsigned long long state = seed + 0xD1B54A32D192ED03ull * (unsigned long long)(h + 1);
@@ -181,8 +186,32 @@ __global__ __launch_bounds__(64) void k_pnp_hypotheses(CameraK K, long long n, c
     }
   }
   double pose[7];
+  if (closed_form) {
+    double P3[9], uv3[6], cand[28];
+    for (int k = 0; k < 3; ++k) {
+      for (int i = 0; i < 3; ++i) P3[3 * k + i] = pts[3 * idx[k] + i];
+      uv3[2 * k] = uv[2 * idx[k]]; uv3[2 * k + 1] = uv[2 * idx[k] + 1];
+    }
+    const int n_cand = p3p_poses(K, P3, uv3, cand);
+    int pick = -1;
+    double pick_err = 0.0;
+    for (int c = 0; c < n_cand; ++c) {
+      double r[2];
+      residual_only(K, cand + 7 * c, pts + 3 * idx[3], uv[2 * idx[3]], uv[2 * idx[3] + 1], r);
+      const double e = r[0] * r[0] + r[1] * r[1];
+      if (e == e && (pick < 0 || e < pick_err)) { pick = c; pick_err = e; }
+    }
+    if (pick < 0) {
+      // no pose puts the three matches on their pixels (or they are collinear): a hypothesis without support
+      count[h] = 0;
+      for (int i = 0; i < 7; ++i) poses[7ll * h + i] = i == 3 ? 1.0 : 0.0;
+      return;
+    }
+    for (int i = 0; i < 7; ++i) pose[i] = cand[7 * pick + i];
+  } else {
 #pragma unroll
-  for (int i = 0; i < 7; ++i) pose[i] = prior[i];
+    for (int i = 0; i < 7; ++i) pose[i] = prior[i];
+  }
   for (int it = 0; it < kPnpGaussNewton; ++it) {
     double H[21], g[6];
 #pragma unroll
@@ -252,48 +281,73 @@ __global__ __launch_bounds__(64) void k_pnp_hypotheses(CameraK K, long long n, c
   for (int i = 0; i < 7; ++i) poses[7ll * h + i] = pose[i];
 }
 
-// out: [0..6] the best hypothesis' pose, [7] its inlier count (as a double); mask: one byte per match
+// cv::RANSACUpdateNumIters (OpenCV's modules/calib3d/src/ptsetreg.cpp): iterations after which a sample free of
+// outliers has been drawn with probability p when a fraction ep of the matches are outliers; never more than max_iters
+__host__ __device__ inline int ransac_update_iterations(double p, double ep, int model_points, int max_iters) {
+  p = fmin(fmax(p, 0.0), 1.0);
+  ep = fmin(fmax(ep, 0.0), 1.0);
+  double num = fmax(1.0 - p, DBL_MIN);
+  double denom = 1.0 - pow(1.0 - ep, (double)model_points);
+  if (denom < DBL_MIN) return 0;
+  num = log(num);
+  denom = log(denom);
+  return denom >= 0.0 || -num >= max_iters * (-denom) ? max_iters : (int)rint(num / denom);
+}
+
+// out: [0..6] the winning hypothesis' pose, [7] its inlier count (as a double; 0 = no hypothesis with a consensus of
+// at least the minimal sample), [8] the number of iterations the sequential loop would have run; mask: one byte per
+// match
+constexpr int kPnpTile = 1024;
 __global__ __launch_bounds__(256) void k_pnp_select(CameraK K, long long n, const double* __restrict__ pts,
                                                     const double* __restrict__ uv, int n_hyp, const int* __restrict__ count,
-                                                    const double* __restrict__ poses, double thr2, double* __restrict__ out,
-                                                    unsigned char* __restrict__ mask) {
-  __shared__ int best_count[256], best_index[256];
+                                                    const double* __restrict__ poses, double thr2, double confidence,
+                                                    double* __restrict__ out, unsigned char* __restrict__ mask) {
+  __shared__ int tile[kPnpTile];
+  __shared__ int s_best, s_best_count, s_limit;
   const int t = threadIdx.x;
-  int bc = -1, bi = 0x7fffffff;
-  for (int h = t; h < n_hyp; h += 256) {
-    const int c = count[h];
-    if (c > bc) { bc = c; bi = h; }  // (ascending h: the first of equals stays)
-  }
-  best_count[t] = bc; best_index[t] = bi;
+  if (t == 0) { s_best = -1; s_best_count = kPnpSample - 1; s_limit = n_hyp; }
   __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if (t < s) {
-      const int oc = best_count[t + s], oi = best_index[t + s];
-      if (oc > best_count[t] || (oc == best_count[t] && oi < best_index[t])) { best_count[t] = oc; best_index[t] = oi; }
+  for (int base = 0; base < n_hyp; base += kPnpTile) {
+    if (base >= s_limit) break;  // (uniform: read behind a barrier)
+    for (int i = t; i < kPnpTile && base + i < n_hyp; i += 256) tile[i] = count[base + i];
+    __syncthreads();
+    if (t == 0) {
+      int best = s_best, bc = s_best_count, limit = s_limit;
+      for (int i = 0; i < kPnpTile && base + i < limit; ++i) {
+        const int c = tile[i];
+        if (c > bc) {
+          bc = c;
+          best = base + i;
+          limit = ransac_update_iterations(confidence, (double)(n - c) / (double)n, kPnpSample, limit);
+        }
+      }
+      s_best = best; s_best_count = bc; s_limit = limit;
     }
     __syncthreads();
   }
-  const int best = best_index[0];
+  const int best = s_best;
   double pose[7];
 #pragma unroll
-  for (int i = 0; i < 7; ++i) pose[i] = poses[7ll * best + i];
+  for (int i = 0; i < 7; ++i) pose[i] = best >= 0 ? poses[7ll * best + i] : (i == 3 ? 1.0 : 0.0);
   if (t < 7) out[t] = pose[t];
-  if (t == 7) out[7] = (double)best_count[0];
+  if (t == 7) out[7] = best >= 0 ? (double)s_best_count : 0.0;
+  if (t == 8) out[8] = (double)s_limit;
   for (long long j = t; j < n; j += 256) {
     double r[2];
     residual_only(K, pose, pts + 3 * j, uv[2 * j], uv[2 * j + 1], r);
-    mask[j] = (r[0] * r[0] + r[1] * r[1] <= thr2) ? 1 : 0;
+    mask[j] = (best >= 0 && r[0] * r[0] + r[1] * r[1] <= thr2) ? 1 : 0;
   }
 }
 
 hipError_t launch_pnp_ransac(const CameraK& K, long long n, const double* d_pts, const double* d_uv, const double* d_prior,
-                             int n_hyp, unsigned long long seed, double reprojection_error, int* d_count, double* d_poses,
-                             double* d_out, unsigned char* d_mask, hipStream_t s) {
+                             int closed_form, int n_hyp, unsigned long long seed, double reprojection_error,
+                             double confidence, int* d_count, double* d_poses, double* d_out, unsigned char* d_mask,
+                             hipStream_t s) {
   const double thr2 = reprojection_error * reprojection_error;
-  hipLaunchKernelGGL(k_pnp_hypotheses, dim3((unsigned)((n_hyp + 63) / 64)), dim3(64), 0, s, K, n, d_pts, d_uv, d_prior, n_hyp,
-                     seed, thr2, d_count, d_poses);
+  hipLaunchKernelGGL(k_pnp_hypotheses, dim3((unsigned)((n_hyp + 63) / 64)), dim3(64), 0, s, K, n, d_pts, d_uv, d_prior,
+                     closed_form, n_hyp, seed, thr2, d_count, d_poses);
   hipLaunchKernelGGL(k_pnp_select, dim3(1), dim3(256), 0, s, K, n, d_pts, d_uv, n_hyp, (const int*)d_count,
-                     (const double*)d_poses, thr2, d_out, d_mask);
+                     (const double*)d_poses, thr2, confidence, d_out, d_mask);
   return hipGetLastError();
 }
 

@@ -18,7 +18,7 @@ ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_OUT_OF_MEMORY, ERR_UNSUPPORTED
     -1, -2, -3, -4, -5, -6, -7)
 EVALUATE_DEVICE_MAX_OBS = 1 << 24  # HIPBA_EVALUATE_DEVICE_MAX_OBS
 CAMERA_Z_FORWARD, CAMERA_X_FORWARD = 0, 1
-ABI_VERSION = 103  # HIPBA_VERSION of the include/hipba.h these ctypes structures mirror
+ABI_VERSION = 104  # HIPBA_VERSION of the include/hipba.h these ctypes structures mirror
 LOSS_NONE, LOSS_HUBER = 0, 1
 LINEAR_AUTO, LINEAR_DENSE_CHOLESKY, LINEAR_PCG = 0, 1, 2
 CONVERGENCE, NO_CONVERGENCE, FAILURE = 0, 1, 2
@@ -184,7 +184,8 @@ def load_library(path=None):
     lib.hipba_refine_pose.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int64,
                                       _dp, _dp, _bp, _dp, C.POINTER(COptions), C.POINTER(CSummary)]
     lib.hipba_pnp_ransac.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int64, _dp, _dp,
-                                     _dp, C.c_int32, C.c_double, C.c_uint64, C.c_int32, _bp, C.POINTER(C.c_int64)]
+                                     _dp, C.c_int32, C.c_double, C.c_double, C.c_uint64, C.c_int32, _bp, C.POINTER(C.c_int64),
+                                     C.POINTER(C.c_int32)]
     lib.hipba_evaluate_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double,
                                           C.c_double, C.c_int32, C.POINTER(COptions), C.c_int, C.c_void_p, C.c_void_p,
@@ -466,22 +467,25 @@ class Solver:
                                            C.byref(o), C.byref(summ)))
         return ps, _summary_dict(summ)
 
-    def pnp_ransac(self, K, points, uv, pose, iterations=1000, reprojection_error=3.0, seed=0, refine=True,
-                   camera_model=CAMERA_Z_FORWARD):
-        """hipba_pnp_ransac (cv::solvePnPRansac as estimator.cpp:28-29 calls it, from a prior pose): (pose, inlier mask)."""
+    def pnp_ransac(self, K, points, uv, pose=None, iterations=1000, reprojection_error=3.0, seed=0, refine=True,
+                   camera_model=CAMERA_Z_FORWARD, confidence=0.99, return_iterations=False):
+        """hipba_pnp_ransac (cv::solvePnPRansac as estimator.cpp:28-29 calls it; pose=None: no prior, minimal samples
+        in closed form; a pose: samples fitted from it): (pose, inlier mask[, iterations the sequential loop runs]).
+        Without a consensus the pose comes back as it went in (zeros when there was none)."""
         pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
         px = np.ascontiguousarray(uv, dtype=np.float64).reshape(-1, 2)
         if pts.shape[0] != px.shape[0]:
             raise ValueError("points and uv differ in length")
-        ps = np.ascontiguousarray(pose, dtype=np.float64).reshape(7).copy()
+        ps = np.zeros(7) if pose is None else np.ascontiguousarray(pose, dtype=np.float64).reshape(7).copy()
         mask = np.zeros(pts.shape[0], dtype=np.uint8)
         cnt = C.c_int64(0)
+        run = C.c_int32(0)
         _check(self._lib.hipba_pnp_ransac(self._h, K[0], K[1], K[2], K[3], camera_model, pts.shape[0],
                                           pts.ctypes.data_as(_dp), px.ctypes.data_as(_dp), ps.ctypes.data_as(_dp),
-                                          int(iterations), float(reprojection_error), int(seed), int(bool(refine)),
-                                          mask.ctypes.data_as(_bp), C.byref(cnt)))
+                                          int(iterations), float(reprojection_error), float(confidence), int(seed),
+                                          int(bool(refine)), mask.ctypes.data_as(_bp), C.byref(cnt), C.byref(run)))
         assert cnt.value == int(mask.sum())
-        return ps, mask
+        return (ps, mask, run.value) if return_iterations else (ps, mask)
 
     def upload(self, problems):
         if isinstance(problems, Problem):

@@ -124,6 +124,54 @@ def test_triangulation_on_device_buffers_equals_the_host_call(solver):
     np.testing.assert_array_equal(got, want)
 
 
+def _x_forward_twin(true):
+    """The pose of an x-forward camera (x ahead, y left, z up: test/ba_test.h:179-211) that sees what the z-forward
+    camera at `true` sees: its axes are the z-forward camera's turned by C = [[0,-1,0],[0,0,-1],[1,0,0]]."""
+    x, y, z, w = true[:4]
+    cx_, cy_, cz_, cw_ = 0.5, -0.5, 0.5, 0.5  # quaternion of C
+    q = np.array([w * cx_ + x * cw_ + y * cz_ - z * cy_, w * cy_ - x * cz_ + y * cw_ + z * cx_,
+                  w * cz_ + x * cy_ - y * cx_ + z * cw_, w * cw_ - x * cx_ - y * cy_ - z * cz_])
+    return np.concatenate([q, true[4:]])
+
+
+def test_oracle_p3p_has_the_true_pose_among_its_solutions(oracle):
+    """Three exact matches: one of the closed-form poses is the camera's, all of them reproject the three points."""
+    for seed, model in ((41, "z"), (42, "z"), (43, "x"), (44, "x")):
+        pts, uv, _, true, _ = scenes.pnp_case(seed, n=3, pixel_sigma=0.0)
+        # (pnp_case rounds its pixels to float: recompute them exactly)
+        cm = oracle.Z_FORWARD
+        one = oracle.Problem(true[None, :].copy(), pts, np.zeros(3, dtype=np.int32), np.arange(3, dtype=np.int32),
+                             np.zeros((3, 2)), scenes.KITTI_K, cm, None, np.ones(3, dtype=np.uint8))
+        uv = oracle.evaluate(one, oracle.JAC_ANALYTIC, apply_loss=False)["residuals"].reshape(3, 2)
+        if model == "x":
+            true, cm = _x_forward_twin(true), oracle.X_FORWARD
+        sols = oracle.p3p_poses(scenes.KITTI_K, pts, uv, cm)
+        assert 1 <= len(sols) <= 4
+        err = []
+        for q in sols:
+            chk = oracle.Problem(q[None, :].copy(), pts, np.zeros(3, dtype=np.int32), np.arange(3, dtype=np.int32), uv,
+                                 scenes.KITTI_K, cm, None, np.ones(3, dtype=np.uint8))
+            assert np.abs(oracle.evaluate(chk, oracle.JAC_ANALYTIC, apply_loss=False)["residuals"]).max() < 1e-6
+            err.append(np.abs(np.sign(q[:4] @ true[:4]) * q[:4] - true[:4]).max() + np.abs(q[4:] - true[4:]).max())
+        assert min(err) < 1e-7
+
+
+def test_oracle_p3p_refuses_collinear_points(oracle):
+    pts = np.array([[0.0, 0.0, 10.0], [1.0, 0.0, 10.0], [2.0, 0.0, 10.0]])
+    uv = np.array([[600.0, 180.0], [670.0, 180.0], [740.0, 180.0]])
+    assert oracle.p3p_poses(scenes.KITTI_K, pts, uv) == []
+
+
+def test_oracle_ransac_iteration_bound(oracle):
+    """cv::RANSACUpdateNumIters by hand: log(1 - p) / log(1 - (1 - ep)^m), rounded, never above the current bound."""
+    assert oracle.ransac_update_iterations(0.99, 0.5, 4, 1000) == 71     # log(0.01) / log(1 - 1/16) = 71.36
+    assert oracle.ransac_update_iterations(0.99, 0.3, 4, 1000) == 17     # log(0.01) / log(1 - 0.2401) = 16.8
+    assert oracle.ransac_update_iterations(0.99, 0.5, 4, 50) == 50       # never more than the bound it had
+    assert oracle.ransac_update_iterations(0.99, 0.0, 4, 1000) == 0      # no outliers: done
+    assert oracle.ransac_update_iterations(0.99, 1.0, 4, 1000) == 1000   # no inliers: no information
+    assert oracle.ransac_update_iterations(1.0, 0.3, 4, 1000) == 1000    # certainty is never reached
+
+
 @pytest.mark.gpu
 def test_pose_refinement_matches_oracle_and_recovers_the_pose(solver, oracle):
     pts, uv, start, true, mask = scenes.pnp_case(5, n=400, outlier_fraction=0.2)
@@ -157,21 +205,56 @@ def test_pose_refinement_rejects_too_few_matches(solver):
 def test_pnp_ransac_matches_oracle_and_finds_the_inliers(solver, oracle):
     # 30 % gross outliers; the prior is half a metre and two degrees off, as the previous frame's pose would be
     pts, uv, start, true, truth_mask = scenes.pnp_case(21, n=300, outlier_fraction=0.3, sigma_t=0.3, sigma_w=0.02)
-    pose, mask = solver.pnp_ransac(scenes.KITTI_K, pts, uv, start, iterations=200, reprojection_error=3.0, seed=7, refine=False)
-    o_pose, o_mask, o_counts = oracle.pnp_ransac(scenes.KITTI_K, pts, uv, start, iterations=200, reprojection_error=3.0, seed=7)
+    pose, mask, run = solver.pnp_ransac(scenes.KITTI_K, pts, uv, start, iterations=200, reprojection_error=3.0, seed=7,
+                                        refine=False, confidence=1.0, return_iterations=True)
+    o_pose, o_mask, o_counts, o_run = oracle.pnp_ransac(scenes.KITTI_K, pts, uv, start, iterations=200, reprojection_error=3.0,
+                                                        seed=7, confidence=1.0)
     # the same samples, the same Gauss-Newton: the same winner, pose to rounding, the same inliers
+    assert run == o_run == 200
     assert np.abs(pose - o_pose).max() <= 1e-8
     assert (mask != o_mask).sum() <= 1 and int(mask.sum()) >= int(o_counts.max()) - 1
     # the consensus set is the true inlier set (0.3 px noise against a 3 px threshold; outliers are uniform in the image)
     assert (mask[truth_mask == 1] == 1).mean() > 0.99 and (mask[truth_mask == 0] == 1).mean() < 0.02
     # refined on the consensus set the pose is the one the true inliers give
-    refined, mask2 = solver.pnp_ransac(scenes.KITTI_K, pts, uv, start, iterations=200, reprojection_error=3.0, seed=7)
+    refined, mask2 = solver.pnp_ransac(scenes.KITTI_K, pts, uv, start, iterations=200, reprojection_error=3.0, seed=7,
+                                       confidence=1.0)
     want, _ = solver.refine_pose(scenes.KITTI_K, pts, uv, pose, use=mask)
     assert np.array_equal(mask, mask2) and np.abs(refined - want).max() <= 1e-9
     assert np.abs(refined[4:] - true[4:]).max() < 0.03 and np.abs(refined[:4] - true[:4]).max() < 2e-3
     # another seed draws other samples and lands on the same consensus set
-    _, mask3 = solver.pnp_ransac(scenes.KITTI_K, pts, uv, start, iterations=200, seed=8)
+    _, mask3 = solver.pnp_ransac(scenes.KITTI_K, pts, uv, start, iterations=200, seed=8, confidence=1.0)
     assert (mask3 != mask).sum() <= 3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ["z_forward", "x_forward"])
+def test_pnp_ransac_without_a_prior_matches_oracle(solver, oracle, model):
+    """The reference's call (estimator.cpp:28-29: rvec = tvec = 0, no extrinsic guess, confidence 0.99): minimal samples
+    in closed form, the confidence bound deciding how far the hypotheses count."""
+    pts, uv, _, true, truth_mask = scenes.pnp_case(31, n=250, outlier_fraction=0.3)
+    cm_e, cm_o = hipba.CAMERA_Z_FORWARD, oracle.Z_FORWARD
+    if model == "x_forward":
+        true = _x_forward_twin(true)
+        cm_e, cm_o = hipba.CAMERA_X_FORWARD, oracle.X_FORWARD
+    pose, mask, run = solver.pnp_ransac(scenes.KITTI_K, pts, uv, None, iterations=300, reprojection_error=3.0, seed=11,
+                                        refine=False, camera_model=cm_e, confidence=0.99, return_iterations=True)
+    o_pose, o_mask, o_counts, o_run = oracle.pnp_ransac(scenes.KITTI_K, pts, uv, None, iterations=300, reprojection_error=3.0,
+                                                        seed=11, camera_model=cm_o, confidence=0.99)
+    # 70 % inliers: log(0.01) / log(1 - 0.7^4) = 17 iterations once a clean sample has been seen
+    assert run == o_run and 10 <= run <= 40
+    sign = np.sign(pose[:4] @ o_pose[:4])
+    assert np.abs(pose * np.concatenate([np.full(4, sign), np.ones(3)]) - o_pose).max() <= 1e-8
+    assert (mask != o_mask).sum() <= 1
+    assert (mask[truth_mask == 1] == 1).mean() > 0.97 and (mask[truth_mask == 0] == 1).mean() < 0.02
+    # every hypothesis in play (confidence 1) can only find as many or more
+    _, mask_all = solver.pnp_ransac(scenes.KITTI_K, pts, uv, None, iterations=300, reprojection_error=3.0, seed=11,
+                                    refine=False, camera_model=cm_e, confidence=1.0)
+    assert int(mask_all.sum()) >= int(mask.sum())
+    # refined on its consensus set the pose is the true one to the noise
+    refined, _ = solver.pnp_ransac(scenes.KITTI_K, pts, uv, None, iterations=300, reprojection_error=3.0, seed=11,
+                                   camera_model=cm_e)
+    s2 = np.sign(refined[:4] @ true[:4])
+    assert np.abs(refined[4:] - true[4:]).max() < 0.03 and np.abs(s2 * refined[:4] - true[:4]).max() < 2e-3
 
 
 @pytest.mark.gpu
@@ -185,6 +268,10 @@ def test_pnp_ransac_without_a_consensus_leaves_the_pose_alone(solver):
     pose, mask = solver.pnp_ransac(scenes.KITTI_K, pts, uv, start, iterations=100, reprojection_error=0.05, seed=3)
     np.testing.assert_array_equal(pose, start)
     assert int(mask.sum()) == 0
+    pose, mask, run = solver.pnp_ransac(scenes.KITTI_K, pts, uv, None, iterations=100, reprojection_error=0.05, seed=3,
+                                        return_iterations=True)
+    np.testing.assert_array_equal(pose, np.zeros(7))
+    assert int(mask.sum()) == 0 and run == 100
 
 
 @pytest.mark.gpu
@@ -196,3 +283,5 @@ def test_pnp_ransac_rejects_bad_arguments(solver):
         solver.pnp_ransac(scenes.KITTI_K, pts, uv, start, iterations=0)
     with pytest.raises(hipba.HipbaError):
         solver.pnp_ransac(scenes.KITTI_K, pts, uv, start, reprojection_error=-1.0)
+    with pytest.raises(hipba.HipbaError):
+        solver.pnp_ransac(scenes.KITTI_K, pts, uv, start, confidence=1.5)

@@ -19,7 +19,7 @@ def test_library_loads_and_exports_header_symbols():
     for name in declared:
         assert hasattr(lib, name), "libhipba.so does not export %s" % name
     assert sorted(hipba.EXPORTED_SYMBOLS) == declared
-    assert lib.hipba_version() == 103 == hipba.ABI_VERSION
+    assert lib.hipba_version() == 104 == hipba.ABI_VERSION
 
 
 def test_options_default_match_ceres_defaults():
