@@ -149,6 +149,9 @@ struct DevP {
   const long long* chunk_start;   // [2 * n_chunks] (begin, end) pair ranges cut at destination boundaries, one wave
                                   // each, longest first
   int n_chunks;
+  const uint4* lane_jobs;         // [n_lane_jobs] off-diagonal blocks of S that one LANE sums (k_schur_gather_lanes):
+                                  // (first pair, pairs, (row slot << 16) | column slot, 0), longest first
+  int n_lane_jobs;
   double* prec;                   // [16 * n_pm_points] landmark record, one 128-byte line: p (3), scale_p (3),
                                   // V^-1 (6), scale_p o (V^-1 g_p) (3), one unused
   double* fw;                     // [n_pm_obs] sqrt(rho') of every observation (robust loss only)

@@ -85,6 +85,42 @@ __host__ __device__ __forceinline__ void projection_jacobians(const CameraK& K, 
   }
 }
 
+// The same Jacobians with the products written out without A's zero entries.
+// With A = d(projection)/d(p_c) (2x3, two of its six entries zero in either camera convention):
+//   Jc = [ -A | A [p_c]x ],  [p_c]x = [[0,-z,y],[z,0,-x],[-y,x,0]];   Jp = A R^T.
+// (The compiler may not drop 0 * x on its own.)  The same values for finite operands, a third fewer multiply-adds;
+// for the kernels whose time is their arithmetic -- the others are tuned to the register count the form above gives.
+__host__ __device__ __forceinline__ void projection_jacobians_sparse(const CameraK& K, const double* Rt, const double* pc, double* Jc,
+                                                     double* Jp) {
+  if (K.model == 0) {
+    const double iz = 1.0 / pc[2];
+    const double a0 = K.fx * iz, a2 = -K.fx * pc[0] * iz * iz;   // row 0: (a0, 0, a2)
+    const double b1 = K.fy * iz, b2 = -K.fy * pc[1] * iz * iz;   // row 1: (0, b1, b2)
+    Jc[0] = -a0; Jc[1] = -0.0; Jc[2] = -a2;
+    Jc[3] = -(a2 * pc[1]); Jc[4] = a2 * pc[0] - a0 * pc[2]; Jc[5] = a0 * pc[1];
+    Jc[6] = -0.0; Jc[7] = -b1; Jc[8] = -b2;
+    Jc[9] = b1 * pc[2] - b2 * pc[1]; Jc[10] = b2 * pc[0]; Jc[11] = -(b1 * pc[0]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      Jp[c] = a0 * Rt[c] + a2 * Rt[6 + c];
+      Jp[3 + c] = b1 * Rt[3 + c] + b2 * Rt[6 + c];
+    }
+  } else {
+    const double ix = 1.0 / pc[0];
+    const double a0 = K.fx * pc[1] * ix * ix, a1 = -K.fx * ix;   // row 0: (a0, a1, 0)
+    const double b0 = K.fy * pc[2] * ix * ix, b2 = -K.fy * ix;   // row 1: (b0, 0, b2)
+    Jc[0] = -a0; Jc[1] = -a1; Jc[2] = -0.0;
+    Jc[3] = a1 * pc[2]; Jc[4] = -(a0 * pc[2]); Jc[5] = a0 * pc[1] - a1 * pc[0];
+    Jc[6] = -b0; Jc[7] = -0.0; Jc[8] = -b2;
+    Jc[9] = -(b2 * pc[1]); Jc[10] = b2 * pc[0] - b0 * pc[2]; Jc[11] = b0 * pc[1];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      Jp[c] = a0 * Rt[c] + a1 * Rt[3 + c];
+      Jp[3 + c] = b0 * Rt[c] + b2 * Rt[6 + c];
+    }
+  }
+}
+
 // residual + tangent-space Jacobians
 __host__ __device__ __forceinline__ void residual_jacobian(const CameraK& K, const double* pose, const double* p, double u, double v,
                                                   double* r, double* Jc, double* Jp) {

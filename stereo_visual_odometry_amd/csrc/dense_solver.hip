@@ -416,7 +416,8 @@ constexpr int LDT = 128 + 16;     // LDS row pitch (doubles): the two k-groups o
 constexpr size_t kGemmNtLds = (size_t)4 * KC * LDT * 8;
 // ENVELOPE: first[i] is the first tile column of tile row i that can be non-zero (monotone in i): of the
 // panel columns [kcol, kcol + K) a tile in row i needs only those from first[i] * NB on -- the factor is zero before
-// them.  Tile row m of the grid is the right-hand side (tile row rhs_tile of the matrix), which is dense.
+// them.  Tile row m of the grid is the right-hand side (tile row rhs_tile of the matrix), which is dense: its tile in
+// column j needs the panel columns from first[j] * NB on.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm_nt(DevP P, double* Amat, int ld, int i0, int j0, int kcol, int K,
                                                  int m, double* fuse_linv, double* fuse_linvt, const int* first,
                                                  int rhs_tile) {
@@ -446,8 +447,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       r = m; c = id - tri;
     }
     ti = r == m ? rhs_tile : i0 + r; tj = j0 + c;
-    if (first && r != m) {
-      const int skip = first[ti] * NB - kcol;
+    if (first) {
+      // (the right-hand side's row is dense, but the other factor of its products is tile row tj of the matrix: the
+      // columns before that row's envelope are not part of the factor -- nothing ever writes them, not even zeros)
+      const int skip = first[r == m ? tj : ti] * NB - kcol;
       if (skip > 0) { kcol += skip; K -= skip; }
       if (K <= 0) return;
     }

@@ -813,6 +813,7 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   // every block of S sum its own products, each recomputed from the landmark's record and the two poses.
   std::vector<uint2> pair_obs, pair_pt;
   std::vector<long long> chunk_start;
+  std::vector<uint4> lane_jobs;
   const bool can_stage = nw == 1 && max_ncam > 20 && max_ncam <= 0xffff && n_pm_obs < 0xffffffffll;
   if (has_long && !can_stage)
     return fail(HIPBA_ERR_UNSUPPORTED, "a landmark with more than %d observations needs a single window of more than 20 "
@@ -866,9 +867,37 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
     // observations, and such a chunk started last would be the tail of the launch
     const long long kGatherChunk = 1024;
     std::vector<std::pair<long long, long long>> chunks;
+    // Off-diagonal blocks have a few dozen pairs each (two poses share the landmarks both were drawn for): one LANE
+    // sums such a block (k_schur_gather_lanes), longest blocks first so that the 64 lanes of a wave finish together.
+    // Diagonal blocks -- as many pairs as the pose has observations, and the right-hand side -- and off-diagonal
+    // ones too long for a lane keep the wave-per-chunk kernel.  HIPBA_GATHER_WAVES=1: everything on that kernel.
+    static const bool waves_only = getenv("HIPBA_GATHER_WAVES") != nullptr;
+    const long long kLaneMaxPairs = 512;
+    const bool lanes = !waves_only && dest_start[n_dest] < 0xffffffffll;
+    std::vector<char> by_lane(lanes ? (size_t)n_dest : 0, 0);
+    if (lanes) {
+      long long dd = 0;
+      for (int si = 0; si < ncam; ++si) {
+        for (int sj = si; sj < ncam; ++sj, ++dd) {
+          const long long len = dest_start[dd + 1] - dest_start[dd];
+          if (sj == si || len == 0 || len > kLaneMaxPairs) continue;
+          by_lane[dd] = 1;
+          lane_jobs.push_back(make_uint4((unsigned)dest_start[dd], (unsigned)len, ((unsigned)si << 16) | (unsigned)sj, 0u));
+        }
+      }
+      std::stable_sort(lane_jobs.begin(), lane_jobs.end(), [](const uint4& x, const uint4& y) { return x.y > y.y; });
+    }
     long long cbeg = 0;
-    for (long long dd = 0; dd < n_dest; ++dd)
-      if (dest_start[dd + 1] - cbeg >= kGatherChunk) { chunks.emplace_back(cbeg, dest_start[dd + 1]); cbeg = dest_start[dd + 1]; }
+    for (long long dd = 0; dd < n_dest; ++dd) {
+      if (lanes && by_lane[dd]) {
+        // (a chunk is a contiguous run of whole blocks: it ends in front of a block that a lane takes)
+        if (cbeg != dest_start[dd]) chunks.emplace_back(cbeg, dest_start[dd]);
+        cbeg = dest_start[dd + 1];
+      } else if (dest_start[dd + 1] - cbeg >= kGatherChunk) {
+        chunks.emplace_back(cbeg, dest_start[dd + 1]);
+        cbeg = dest_start[dd + 1];
+      }
+    }
     if (cbeg != dest_start[n_dest]) chunks.emplace_back(cbeg, dest_start[n_dest]);
     std::stable_sort(chunks.begin(), chunks.end(), [](const std::pair<long long, long long>& x, const std::pair<long long, long long>& y) {
       return x.second - x.first > y.second - y.first;
@@ -1044,7 +1073,7 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   long long *d_cm_start, *d_pp_start;
   double *d_cm_uv, *d_obs_uv;
   BlockDesc* d_blocks; unsigned short* d_pairs; WinDesc* d_wd; RunDesc* d_runs;
-  uint2 *d_pair_obs = nullptr, *d_pair_pt = nullptr; long long* d_chunk_start = nullptr;
+  uint2 *d_pair_obs = nullptr, *d_pair_pt = nullptr; long long* d_chunk_start = nullptr; uint4* d_lane_jobs = nullptr;
   // parameters (both buffers) and the window states first and next to each other: they arrive with the upload (the
   // candidate buffers as copies, the states as zeros) and leave in one copy at the end of a solve
   up.add(&P.poses[0], poses.size());
@@ -1067,7 +1096,7 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   up.add(&d_pairs, std::max<size_t>(pairs.size(), 1));
   up.add(&d_wd, wd.size());
   up.add(&d_runs, std::max<size_t>(runs.size(), 1));
-  if (staged) { up.add(&d_pair_obs, pair_obs.size()); up.add(&d_pair_pt, pair_pt.size()); up.add(&d_chunk_start, chunk_start.size()); }
+  if (staged) { up.add(&d_pair_obs, pair_obs.size()); up.add(&d_pair_pt, pair_pt.size()); up.add(&d_chunk_start, chunk_start.size()); up.add(&d_lane_jobs, lane_jobs.size()); }
   LongDesc* d_longs = nullptr;
   up.add(&d_longs, std::max<size_t>(longs.size(), 1));
   const size_t upload_bytes = up.total;
@@ -1125,6 +1154,7 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
   P.blocks = d_blocks; P.pairs = d_pairs; P.wd = d_wd; P.runs = d_runs;
   P.pair_obs = d_pair_obs; P.pair_pt = d_pair_pt; P.chunk_start = d_chunk_start;
   P.n_chunks = staged ? (int)(chunk_start.size() / 2) : 0;
+  P.lane_jobs = d_lane_jobs; P.n_lane_jobs = staged ? (int)lane_jobs.size() : 0;
   P.dest_owned = dest_owned ? 1 : 0;
   if (!staged) { P.prec = nullptr; P.fw = nullptr; P.cam_tab = nullptr; }
 
@@ -1157,10 +1187,16 @@ int build_resident(hipba_handle_s* h, int nw, const hipba_problem* probs, bool u
     stage(d_pair_obs, pair_obs.data(), pair_obs.size() * sizeof(uint2));
     stage(d_pair_pt, pair_pt.data(), pair_pt.size() * sizeof(uint2));
     stage(d_chunk_start, chunk_start.data(), chunk_start.size() * 8);
+    stage(d_lane_jobs, lane_jobs.data(), lane_jobs.size() * sizeof(uint4));
   }
   hipStream_t s = h->stream;
   SETUP_MARK("fill staging");
   hipError_t e = hipMemcpyAsync(R->arena, h->staging, upload_bytes, hipMemcpyHostToDevice, s);
+  // development switch: HIPBA_POISON_WORKSPACE=1 fills every work array behind the uploaded part with NaN patterns, so
+  // that a kernel reading a word nobody has written shows up in the result (a reused arena holds the last problem's)
+  static const bool poison = getenv("HIPBA_POISON_WORKSPACE") != nullptr;
+  if (poison && e == hipSuccess && total > upload_bytes)
+    e = hipMemsetAsync(static_cast<char*>(R->arena) + upload_bytes, 0xFF, total - upload_bytes, s);
   if (!use_handle_arena) {  // (a one-shot solve is never reset)
     if (e == hipSuccess) e = hipMemcpyAsync(R->poses0, P.poses[0], poses.size() * 8, hipMemcpyDeviceToDevice, s);
     if (e == hipSuccess) e = hipMemcpyAsync(R->points0, P.points[0], points.size() * 8, hipMemcpyDeviceToDevice, s);

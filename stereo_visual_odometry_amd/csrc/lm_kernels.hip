@@ -1091,6 +1091,123 @@ __global__ __launch_bounds__(kBlock) void k_schur_gather(DevP P, LmParams lm) {
   flush();
 }
 
+// gathered mode, off-diagonal blocks: ONE LANE per block of S.  The pairs of a block sit together in the
+// destination-ordered list and there are a few dozen of them (two poses share the landmarks both happened to be
+// drawn for), so a lane walks its block's pairs one after the other with the block in 36 registers: no transposition
+// through LDS, no segmented sums, no synchronisation at all, and the two poses' rows of the camera table are loaded
+// once per block instead of once per pair.  The column scales of the two poses are the same for every pair of a block:
+// they multiply the sum once at the end.  The loads run ahead of the arithmetic -- the list entry (and a robust
+// loss's two observation numbers) two pairs ahead, the landmark's record (and the two weights) one pair ahead.
+// Blocks come longest first, 64 neighbours of the sorted list to a wave, so the lanes of a wave finish together.
+// One writer per block, pairs summed in list order: reproducible run to run.  Diagonal blocks (thousands of pairs
+// each, and the right-hand side) stay with k_schur_gather.
+__global__ __launch_bounds__(kBlock) void k_schur_gather_lanes(DevP P, LmParams lm) {
+  if (!P.ws[0].active) return;
+  const int n_jobs = P.n_lane_jobs;
+  const int gid = blockIdx.x * kBlock + threadIdx.x;
+  const uint4 job = P.lane_jobs[gid < n_jobs ? gid : n_jobs - 1];
+  const int len = gid < n_jobs ? (int)job.y : 0;
+  const long long q0 = job.x;
+  const int a = (int)(job.z >> 16), b = (int)(job.z & 0xffffu);
+  const CameraK K = P.wd[0].K;
+  const double* cam_tab = P.cam_tab + 18ll * P.wd[0].cam_base;
+  const bool robust = lm.loss != HIPBA_LOSS_NONE;
+  typedef double v2d __attribute__((ext_vector_type(2)));
+  double RA[12], RB[12];  // R^T (9) and R^T t (3) of the two poses, for all of the block's pairs
+  {
+    const v2d* ca = reinterpret_cast<const v2d*>(cam_tab + 18ll * a);
+    const v2d* cb = reinterpret_cast<const v2d*>(cam_tab + 18ll * b);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const v2d x = ca[i], y = cb[i];
+      RA[2 * i] = x.x; RA[2 * i + 1] = x.y; RB[2 * i] = y.x; RB[2 * i + 1] = y.y;
+    }
+  }
+  double acc[36];
+#pragma unroll
+  for (int i = 0; i < 36; ++i) acc[i] = 0.0;
+  // (an index past the block's last pair reads its first pair again: loaded, never used)
+  auto entry = [&](int it) { return P.pair_pt[q0 + (it < len ? it : 0)].x & 0x7fffffffu; };
+  auto obs_of = [&](int it) { return P.pair_obs[q0 + (it < len ? it : 0)]; };
+  auto record = [&](unsigned pp, v2d* r) {
+    const v2d* src = reinterpret_cast<const v2d*>(P.prec + 16ll * pp);
+#pragma unroll
+    for (int m = 0; m < 6; ++m) r[m] = src[m];  // p (3), scale_p (3), V^-1 (6): the first twelve words
+  };
+  v2d rec_next[6];
+  record(entry(0), rec_next);
+  unsigned ent_next = entry(1);
+  uint2 po_next = make_uint2(0u, 0u);
+  double fa_next = 1.0, fb_next = 1.0;
+  if (robust) {
+    const uint2 po = obs_of(0);
+    fa_next = P.fw[po.x]; fb_next = P.fw[po.y];
+    po_next = obs_of(1);
+  }
+  for (int it = 0; __any(it < len); ++it) {
+    double rec[12];
+#pragma unroll
+    for (int m = 0; m < 6; ++m) { rec[2 * m] = rec_next[m].x; rec[2 * m + 1] = rec_next[m].y; }
+    double wgt = 1.0;
+    if (robust) {
+      wgt = fa_next * fb_next;
+      wgt *= wgt;
+      fa_next = P.fw[po_next.x]; fb_next = P.fw[po_next.y];
+      po_next = obs_of(it + 2);
+    }
+    record(ent_next, rec_next);
+    ent_next = entry(it + 2);
+    if (it < len) {
+      double pc[3], JcA[12], JpA[6], JcB[12], JpB[6];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) pc[i] = RB[3 * i] * rec[0] + RB[3 * i + 1] * rec[1] + RB[3 * i + 2] * rec[2] - RB[9 + i];
+      projection_jacobians_sparse(K, RB, pc, JcB, JpB);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) pc[i] = RA[3 * i] * rec[0] + RA[3 * i + 1] * rec[1] + RA[3 * i + 2] * rec[2] - RA[9 + i];
+      projection_jacobians_sparse(K, RA, pc, JcA, JpA);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const double sp = rec[3 + i];
+        JpA[i] *= sp; JpA[3 + i] *= sp; JpB[i] *= sp; JpB[3 + i] *= sp;
+      }
+      const double* Vi = rec + 6;
+      double T[12];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const double c0 = JpA[3 * k] * Vi[0] + JpA[3 * k + 1] * Vi[1] + JpA[3 * k + 2] * Vi[2];
+        const double c1 = JpA[3 * k] * Vi[1] + JpA[3 * k + 1] * Vi[3] + JpA[3 * k + 2] * Vi[4];
+        const double c2 = JpA[3 * k] * Vi[2] + JpA[3 * k + 1] * Vi[4] + JpA[3 * k + 2] * Vi[5];
+        const double m0 = (c0 * JpB[0] + c1 * JpB[1] + c2 * JpB[2]) * wgt;
+        const double m1 = (c0 * JpB[3] + c1 * JpB[4] + c2 * JpB[5]) * wgt;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) T[6 * k + c] = m0 * JcB[c] + m1 * JcB[6 + c];
+      }
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) acc[6 * r + c] = fma(JcA[6 + r], T[6 + c], fma(JcA[r], T[c], acc[6 * r + c]));
+    }
+  }
+  if (len <= 0) return;
+  double sa[6], sb[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { sa[i] = cam_tab[18ll * a + 12 + i]; sb[i] = cam_tab[18ll * b + 12 + i]; }
+  if (P.dense_S) {
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      double* dst = P.dense_S + (long long)(6 * a + r) * P.dense_ld + 6 * b;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) dst[c] = -(sa[r] * sb[c]) * acc[6 * r + c];
+    }
+  } else {
+    double* dst = P.S + P.wd[0].S_off + 36ll * tri_index(a, b, P.wd[0].ncam);
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) dst[6 * r + c] = -(sa[r] * sb[c]) * acc[6 * r + c];
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // back-substitution + model cost change + candidate landmarks, all active blocks:
 //   y_p = V^-1 (g_p - sum W^T y_c),  step = -y,  delta = step * scale,
@@ -2507,6 +2624,8 @@ hipError_t launch_point_schur(const DevP& P, const LmParams& lm, int small_ncam,
     const size_t gather_lds = (size_t)(kBlock / 64) * kGatherLds * 8;
     const unsigned grid = (unsigned)((P.n_chunks + kBlock / 64 - 1) / (kBlock / 64));
     if (grid) hipLaunchKernelGGL(k_schur_gather, dim3(grid), dim3(kBlock), gather_lds, s, P, lm);
+    if (P.n_lane_jobs > 0)
+      hipLaunchKernelGGL(k_schur_gather_lanes, dim3((unsigned)((P.n_lane_jobs + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, P, lm);
   } else if (small_ncam > 0 && P.dest_owned) {
     if (parts < 1) parts = 1;
     const int dgroups = owned_dest_groups(small_ncam);
