@@ -97,7 +97,7 @@ SHADER_CLOCK_GHZ = 2.4   # MI355X peak engine clock
 SIMDS = 1024             # 256 compute units x 4
 # bench.py's kernel names -> the kernels (as rocprofv3 names them) one launch is made of
 ISSUE_MEMBERS = {"residual": ["k_cost"], "residual_jacobian": ["k_residual_jacobian"], "camera_blocks": ["k_camera_blocks"],
-                 "point_schur": ["k_point_schur<2>", "k_schur_gather"], "backsub": ["k_backsub<true>"]}
+                 "point_schur": ["k_point_schur<2>", "k_schur_gather", "k_schur_gather_lanes"], "backsub": ["k_backsub<true>"]}
 
 
 def load_issue(workload_key):
