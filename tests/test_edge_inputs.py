@@ -128,3 +128,56 @@ def test_repeated_calls_hold_device_memory_steady(solver):
     for rep in range(1, 6):
         one_pass(rep)
     assert free_bytes() == before
+
+
+_POISON_SCRIPT = r"""
+import sys, json
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from stereo_visual_odometry_amd import hipba, scenes
+import test_headline_parity as T
+s = hipba.Solver(0)
+out = {}
+banded = T._shuffled_cameras(T.banded_scene(), 1)
+small = scenes.small_window(41, n_frames=8, n_points=600)[0]
+kitti = scenes.kitti_like_window(42)[0]
+for name, prob, opts in (("kitti", kitti, hipba.reference_production_options()),
+                         ("banded", banded, hipba.default_options(max_num_iterations=8)),
+                         ("small", small, hipba.reference_production_options()),
+                         ("banded_again", banded, hipba.default_options(max_num_iterations=8))):
+    g = prob.copy()
+    r = s.solve(g, opts)
+    out[name] = [r["termination_type"], r["final_cost"], len(r["iterations"])]
+batch = [scenes.small_window(50 + i, n_frames=6 + i, n_points=300)[0] for i in range(5)]
+res = s.solve_batched(batch, hipba.reference_production_options())
+out["batch"] = [[r["termination_type"], r["final_cost"]] for r in res]
+print("RESULT " + json.dumps(out))
+"""
+
+
+@pytest.mark.gpu
+def test_no_kernel_reads_a_word_nobody_wrote():
+    """A handle's arena is reused from call to call and holds the last problem's data; HIPBA_POISON_WORKSPACE fills
+    every work array with NaN patterns at upload instead.  Windows of every kind solved back to back on one handle, in
+    two processes -- with and without the poison: the same terminations and costs.  (The dense solver once multiplied
+    the right-hand side's row with the panel columns in front of a matrix row's envelope, which nothing writes: right
+    on zeroed memory, wrong behind another problem.)"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for poison in (False, True):
+        env = dict(os.environ)
+        env.pop("HIPBA_POISON_WORKSPACE", None)
+        if poison:
+            env["HIPBA_POISON_WORKSPACE"] = "1"
+        p = subprocess.run([sys.executable, "-c", _POISON_SCRIPT, root], capture_output=True, text=True, timeout=110, env=env)
+        assert p.returncode == 0, p.stderr[-2000:]
+        line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1]
+        got[poison] = json.loads(line[len("RESULT "):])
+    clean, dirty = got[False], got[True]
+    assert clean.keys() == dirty.keys()
+    for k in ("kitti", "banded", "small", "banded_again"):
+        assert clean[k][0] == dirty[k][0] and clean[k][2] == dirty[k][2], k
+        assert np.isfinite(dirty[k][1]) and abs(clean[k][1] - dirty[k][1]) <= 1e-9 * abs(clean[k][1]), k
+    for a, b in zip(clean["batch"], dirty["batch"]):
+        assert a[0] == b[0] and abs(a[1] - b[1]) <= 1e-9 * abs(a[1])
