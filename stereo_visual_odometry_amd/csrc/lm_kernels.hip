@@ -993,15 +993,23 @@ __global__ __launch_bounds__(kBlock) void k_schur_gather(DevP P, LmParams lm) {
     for (int k = 0; k < 15; ++k) rec[k] = sT[lane * kGatherRec + k];
     HIPBA_WAVE_SYNC();  // records are in registers; the words are free for the products
     double JcA[12], JpA[6], JcB[12], JpB[6];
+    const bool self = (pe.x >> 31) != 0u;
     gather_side(K, camA, rec, JcA, JpA);
-    gather_side(K, camB, rec, JcB, JpB);
+    if (__all(self)) {
+      // a batch inside a diagonal block: every pair is an observation with itself, both sides are the same
+#pragma unroll
+      for (int i = 0; i < 12; ++i) JcB[i] = JcA[i];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) JpB[i] = JpA[i];
+    } else {
+      gather_side(K, camB, rec, JcB, JpB);
+    }
     const int diag = a == b ? 1 : 0;
     // A pair of an observation with itself also carries that observation's term of the reduced right-hand side,
     // Jc^T Jp (V^-1 g_p) with scale_p o (V^-1 g_p) from the record and the landmark columns still unscaled.  Only
     // the upper triangle of a diagonal block is kept, so six of the words below its diagonal carry these instead
     // and are summed with the block, in the same fixed order, by the same single writer.
     double bq[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    const bool self = (pe.x >> 31) != 0u;
     if (__any(self)) {
       const double ws = self ? wgt_rhs : 0.0;  // two different observations by one pose: the block only
       const double m0 = (JpA[0] * rec[12] + JpA[1] * rec[13] + JpA[2] * rec[14]) * ws;
