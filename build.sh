@@ -32,3 +32,5 @@ g++ -O2 -std=c++17 -Wall -pthread -Iinclude -I$SRC/host -o $OUT/host_selftest $S
 echo "built $OUT/host_selftest"
 g++ -O2 -std=c++17 -Wall -pthread -Iinclude -I$SRC/host -o $OUT/kitti_runner $SRC/host/kitti_runner_cli.cpp -L$OUT -lhipba -Wl,-rpath,'$ORIGIN'
 echo "built $OUT/kitti_runner"
+g++ -O2 -std=c++17 -Wall -Iinclude -I$SRC/host -o $OUT/frontend_steps $SRC/host/frontend_steps_cli.cpp -L$OUT -lhipba -Wl,-rpath,'$ORIGIN'
+echo "built $OUT/frontend_steps"

@@ -4,7 +4,9 @@
 // compiles unchanged against the real headers:
 //   VO::Map       landmarks_, frames_, insertFrame, insertLandmark,
 //                 cleanMap                                           (sensor/map.hpp:13-25, map.cpp:8-50)
-//   VO::Frame     pose_, features_left_, pushFeatureLeftWithLandmark (sensor/frame.hpp:15-39, frame.cpp:20-25)
+//   VO::Frame     pose_, features_left_, features_right_, pushFeatureLeft[WithLandmark], getPointsLeft2D / 3D
+//                                                                    (sensor/frame.hpp:15-39, frame.cpp:5-50)
+//   VO::Context   frame_prev_, frame_curr_                           (sensor/context.hpp:13-27, without the images)
 //   VO::Feature   frame_, pixel, landmark_                           (sensor/feature.hpp:15-33)
 //   VO::MapPoint  pose_, observations_                               (sensor/map_point.hpp:12-22)
 //   SE3d::data()  7 doubles qx qy qz qw tx ty tz                     (Sophus::SE3d as used at optimizer.cpp:27)
@@ -19,6 +21,7 @@
 namespace VO {
 
 struct Point2f { float x = 0.f, y = 0.f; };                       // cv::Point2f
+struct Point3f { float x = 0.f, y = 0.f, z = 0.f; };              // cv::Point3f
 struct Matx33d {                                                   // cv::Matx33d (row-major)
   double val[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   double operator()(int r, int c) const { return val[3 * r + c]; }
@@ -71,12 +74,41 @@ public:
 class Frame : public std::enable_shared_from_this<Frame> {
 public:
   std::vector<std::shared_ptr<Feature>> features_left_;
+  std::vector<Point2f> features_right_;
   SE3d pose_;
+  // frame.cpp:5-8, 27-37: the pixels of the left features from start_idx on
+  std::vector<Point2f> getPointsLeft2D(std::size_t start_idx) const {
+    std::vector<Point2f> points;
+    points.reserve(features_left_.size() - start_idx);
+    for (std::size_t i = start_idx; i < features_left_.size(); ++i) points.push_back(features_left_[i]->pixel);
+    return points;
+  }
+  // frame.cpp:10-13, 39-50: the landmarks of the left features, in single precision as cv::Point3f holds them
+  std::vector<Point3f> getPointsLeft3D() const {
+    std::vector<Point3f> points;
+    points.reserve(features_left_.size());
+    for (const auto& feature : features_left_) {
+      Point3f q;
+      q.x = (float)feature->landmark_->pose_.x(); q.y = (float)feature->landmark_->pose_.y(); q.z = (float)feature->landmark_->pose_.z();
+      points.push_back(q);
+    }
+    return points;
+  }
+  void pushFeatureLeft(const Point2f& point_2d) {  // frame.cpp:15-18
+    features_left_.push_back(std::make_shared<Feature>(shared_from_this(), point_2d, nullptr));
+  }
   void pushFeatureLeftWithLandmark(const Point2f& point_2d, const std::shared_ptr<MapPoint>& landmark) {
     auto f = std::make_shared<Feature>(shared_from_this(), point_2d, landmark);
     features_left_.push_back(f);
     landmark->observations_.push_back(f);
   }
+};
+
+class Context {  // sensor/context.hpp:13-27 (the frames only: images stay with the OpenCV frontend)
+public:
+  std::shared_ptr<Frame> frame_prev_{nullptr};
+  std::shared_ptr<Frame> frame_curr_{nullptr};
+  void insertFrame(const std::shared_ptr<Frame>& frame) { frame_prev_ = frame_curr_; frame_curr_ = frame; }
 };
 
 class Map {

@@ -285,3 +285,24 @@ def test_pnp_ransac_rejects_bad_arguments(solver):
         solver.pnp_ransac(scenes.KITTI_K, pts, uv, start, reprojection_error=-1.0)
     with pytest.raises(hipba.HipbaError):
         solver.pnp_ransac(scenes.KITTI_K, pts, uv, start, confidence=1.5)
+
+
+@pytest.mark.gpu
+def test_triangulator_and_estimator_adapters_on_a_stereo_pair_of_frames():
+    """VO::Triangulator::triangulate and VO::Estimator::estimate as the per-frame pipeline calls them
+    (src/frontend.cpp:34-47), through the drop-in classes of csrc/host/frontend_steps.hpp: landmarks from the previous
+    frame's stereo matches enter the map, the current frame's pose comes from them by sample consensus without a
+    prior, the features that were wrong matches are dropped (estimator.cpp:31-45), an implausible motion is refused
+    and leaves the frame alone (estimator.cpp:60-65).  The program checks itself against its scene's truth."""
+    import os, re, subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "stereo_visual_odometry_amd", "lib",
+                       "frontend_steps")
+    r = subprocess.run([exe, "600", "0.25"], capture_output=True, text=True, timeout=110)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "ALL OK" in r.stdout
+    kept, total, planted = map(int, re.search(r"(\d+) of (\d+) features kept \((\d+) wrong", r.stdout).groups())
+    assert total == 600 and abs(kept - (total - planted)) <= 3
+    assert "implausible motion (100 m against a bound of 50): refused" in r.stdout
+    # another share of wrong matches, another size
+    r = subprocess.run([exe, "250", "0.4"], capture_output=True, text=True, timeout=110)
+    assert r.returncode == 0, r.stdout + r.stderr
