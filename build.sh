@@ -34,3 +34,5 @@ g++ -O2 -std=c++17 -Wall -pthread -Iinclude -I$SRC/host -o $OUT/kitti_runner $SR
 echo "built $OUT/kitti_runner"
 g++ -O2 -std=c++17 -Wall -Iinclude -I$SRC/host -o $OUT/frontend_steps $SRC/host/frontend_steps_cli.cpp -L$OUT -lhipba -Wl,-rpath,'$ORIGIN'
 echo "built $OUT/frontend_steps"
+g++ -O2 -std=c++17 -Wall -Iinclude -I$SRC/host -o $OUT/vo_pipeline $SRC/host/vo_pipeline_cli.cpp -L$OUT -lhipba -Wl,-rpath,'$ORIGIN'
+echo "built $OUT/vo_pipeline"

@@ -148,3 +148,40 @@ def test_kitti_runner_over_a_sequence_directory(tmp_path):
     # a sequence directory that is not there
     bad = subprocess.run([exe, d + "_missing"], capture_output=True, text=True)
     assert bad.returncode == 1 and "Could not open file" in bad.stderr
+
+
+@pytest.mark.gpu
+def test_whole_pipeline_with_the_gpu_steps(tmp_path):
+    """The reference's main loop (src/main.cpp:45-58) and Frontend::visualOdometryPipeline (src/frontend.cpp:22-86) line
+    by line, with Triangulator::triangulate, Estimator::estimate and Optimizer::optimize on the GPU and the image half
+    (FAST, Lucas-Kanade: OpenCV, absent here) replaced by a scene of known landmarks with pixel noise, lost tracks and
+    wrong matches (csrc/host/synthetic_frontend.hpp).  200 frames at 0.8 m each: the trajectory stays within a fraction
+    of a percent of the distance travelled without bundle adjustment and a few percent with it (the reference's
+    left-image-only bundle adjustment, anchored by the first frame's landmarks alone, does not improve a stereo odometry
+    this accurate), windows are solved where frontend.cpp:71 says, nothing
+    is reset, and the trajectory bookkeeping (frontend.cpp:74-81) has one entry per step."""
+    exe = os.path.join(LIB, "vo_pipeline")
+    r = subprocess.run([exe, "--frames", "200", "--both"], capture_output=True, text=True, timeout=200)
+    assert r.returncode == 0, r.stderr
+    lines = [l.split() for l in r.stdout.strip().split("\n") if l.startswith("bundle_adjustment")]
+    get = lambda f, k: float(f[f.index(k) + 1])
+    off, on = lines
+    assert off[1] == "off" and on[1] == "on"
+    assert get(off, "windows") == 0 and get(on, "windows") == 9          # iterations 20, 40, ... 180
+    assert get(off, "resets") == 0 and get(on, "resets") == 0
+    # 160 m travelled.  Repeated runs of this very sequence gave 0.07-0.26 m without and 0.14-0.95 m with bundle
+    # adjustment (the consensus amplifies last-bit differences of the solves, so runs differ): bounds with room
+    assert get(off, "ate_rmse_m") < 1.0 and get(on, "ate_rmse_m") < 4.0
+    assert get(off, "trajectory_entries") == 199
+    assert get(off, "mean_features") > 500                                 # min_num_features_ (frontend.hpp:30)
+    # along a KITTI-layout sequence's ground truth, with its calibration
+    d, gt = _write_curved_sequence(tmp_path)
+    r = subprocess.run([exe, "--kitti-dir", d, "--poses", gt, "--frames", "120"], capture_output=True, text=True, timeout=200)
+    assert r.returncode == 0, r.stderr
+    on = [l.split() for l in r.stdout.strip().split("\n") if l.startswith("bundle_adjustment")][0]
+    assert get(on, "windows") == 5 and get(on, "resets") == 0 and get(on, "ate_rmse_m") < 4.0
+    # heavy mismatching: a quarter of the tracks wrong every frame; the consensus still finds the motion
+    r = subprocess.run([exe, "--frames", "80", "--wrong", "0.25", "--no-ba"], capture_output=True, text=True, timeout=200)
+    assert r.returncode == 0, r.stderr
+    off = [l.split() for l in r.stdout.strip().split("\n") if l.startswith("bundle_adjustment")][0]
+    assert get(off, "resets") == 0 and get(off, "ate_rmse_m") < 1.0
