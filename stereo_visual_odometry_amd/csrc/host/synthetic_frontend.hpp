@@ -217,6 +217,7 @@ public:
     estimator_->max_delta_pose_norm_ = max_delta_pose_norm_;
     estimator_->verbose_ = verbose_;
     optimizer_.progress_to_stdout_ = false;
+    engine_->get();  // (the engine handle is created here, not inside the first frame's triangulation)
   }
 
   void visualOdometryPipeline() {  // frontend.cpp:22-86
