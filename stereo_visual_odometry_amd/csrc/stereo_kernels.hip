@@ -159,6 +159,7 @@ hipError_t launch_se3_plus(long long n, const double* d_poses, const double* d_d
 // way OpenCV's sequential loop does (a better one shrinks the number of iterations still to run by the confidence
 // bound, hypotheses past the bound do not count), takes the best (the lowest number among equals) and marks its
 // inliers.  Every hypothesis is evaluated, all at once; the bound only decides which of them the answer may come from.
+// Three launches: the fits (a lane per hypothesis), their support (a workgroup per hypothesis), the choice.
 __host__ __device__ __forceinline__ unsigned long long splitmix64(unsigned long long& state) {
   unsigned long long z = (state += 0x9E3779B97F4A7C15ull);
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(64) void k_pnp_hypotheses(CameraK K, long long n, c
     }
     if (pick < 0) {
       // no pose puts the three matches on their pixels (or they are collinear): a hypothesis without support
-      count[h] = 0;
+      count[h] = -1;
       for (int i = 0; i < 7; ++i) poses[7ll * h + i] = i == 3 ? 1.0 : 0.0;
       return;
     }
@@ -270,15 +271,37 @@ __global__ __launch_bounds__(64) void k_pnp_hypotheses(CameraK K, long long n, c
     for (int i = 0; i < 6; ++i) step2 += dlt[i] * dlt[i];
     if (!(step2 > 1e-24)) break;  // converged (or not a number: the count below is zero then)
   }
+  count[h] = 0;  // (k_pnp_count fills it in)
+#pragma unroll
+  for (int i = 0; i < 7; ++i) poses[7ll * h + i] = pose[i];
+}
+
+// The support of every hypothesis: one workgroup per hypothesis, its lanes striding over the matches (a lane per
+// hypothesis walking all matches alone took ten times the fit itself).  A hypothesis without a pose (count -1) gets 0.
+__global__ __launch_bounds__(256) void k_pnp_count(CameraK K, long long n, const double* __restrict__ pts,
+                                                   const double* __restrict__ uv, const double* __restrict__ poses, double thr2,
+                                                   int* __restrict__ count) {
+  __shared__ int partial[4];
+  const int h = blockIdx.x;
+  if (count[h] < 0) {  // (uniform over the workgroup)
+    __syncthreads();   // every lane has read the mark before lane 0 overwrites it
+    if (threadIdx.x == 0) count[h] = 0;
+    return;
+  }
+  double pose[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) pose[i] = poses[7ll * h + i];
   int c = 0;
-  for (long long j = 0; j < n; ++j) {
+  for (long long j = threadIdx.x; j < n; j += 256) {
     double r[2];
     residual_only(K, pose, pts + 3 * j, uv[2 * j], uv[2 * j + 1], r);
     c += (r[0] * r[0] + r[1] * r[1] <= thr2) ? 1 : 0;
   }
-  count[h] = c;
 #pragma unroll
-  for (int i = 0; i < 7; ++i) poses[7ll * h + i] = pose[i];
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+  if ((threadIdx.x & 63) == 0) partial[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) count[h] = partial[0] + partial[1] + partial[2] + partial[3];
 }
 
 // cv::RANSACUpdateNumIters (OpenCV's modules/calib3d/src/ptsetreg.cpp): iterations after which a sample free of
@@ -346,6 +369,7 @@ hipError_t launch_pnp_ransac(const CameraK& K, long long n, const double* d_pts,
   const double thr2 = reprojection_error * reprojection_error;
   hipLaunchKernelGGL(k_pnp_hypotheses, dim3((unsigned)((n_hyp + 63) / 64)), dim3(64), 0, s, K, n, d_pts, d_uv, d_prior,
                      closed_form, n_hyp, seed, thr2, d_count, d_poses);
+  hipLaunchKernelGGL(k_pnp_count, dim3((unsigned)n_hyp), dim3(256), 0, s, K, n, d_pts, d_uv, (const double*)d_poses, thr2, d_count);
   hipLaunchKernelGGL(k_pnp_select, dim3(1), dim3(256), 0, s, K, n, d_pts, d_uv, n_hyp, (const int*)d_count,
                      (const double*)d_poses, thr2, confidence, d_out, d_mask);
   return hipGetLastError();
