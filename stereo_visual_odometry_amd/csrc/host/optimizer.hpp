@@ -7,6 +7,7 @@
 // so the same header compiles against the reference's real Map (Sophus/Eigen/OpenCV types) or against the
 // dependency-free stand-ins of vo_types.hpp.
 #pragma once
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <memory>
@@ -121,8 +122,10 @@ public:
     hipba_options_default(&options);
     options.max_num_iterations = 300;          // optimizer.cpp:58
     options.minimizer_progress_to_stdout = progress_to_stdout_ ? 1 : 0;  // optimizer.cpp:56 (+ the report of line 62)
+    const auto t0 = std::chrono::steady_clock::now();
     FlatWindow w;
     flattenMap(map, K, HIPBA_CAMERA_Z_FORWARD, /*first_frame_constant=*/true, &w);
+    const auto t1 = std::chrono::steady_clock::now();
     if (!dump_directory_.empty()) {
       // capture hook: the window exactly as the solver receives it, for replay on a machine without the frontend
       char name[64];
@@ -133,8 +136,12 @@ public:
     hipba_summary summary{};
     if (hipba_solve(handle_, &w.problem, &options, &summary) != HIPBA_OK)
       throw std::runtime_error(std::string("hipba_solve: ") + hipba_last_error());
+    const auto t2 = std::chrono::steady_clock::now();
     if (summary.termination_type != HIPBA_FAILURE) writeBack(w);
     last_summary_ = summary;
+    last_flatten_ms_ = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    last_solve_ms_ = std::chrono::duration<double, std::milli>(t2 - t1).count();
+    last_write_back_ms_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t2).count();
   }
 
   int device_ = 0;
@@ -143,6 +150,8 @@ public:
   bool dump_binary_ = false;
   int num_calls_ = 0;
   hipba_summary last_summary_{};
+  // where the last call's time went: walking the map into arrays, the engine (a window dump included), copying back
+  double last_flatten_ms_ = 0.0, last_solve_ms_ = 0.0, last_write_back_ms_ = 0.0;
 
 private:
   hipba_handle handle_ = nullptr;

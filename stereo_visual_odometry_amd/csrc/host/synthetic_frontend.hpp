@@ -256,8 +256,9 @@ public:
       ++num_optimizations_;
       if (verbose_) {
         const hipba_summary& su = optimizer_.last_summary_;
-        printf("bundle adjustment %d: %zu frames, cost %.6g -> %.6g, %d iterations, termination %d\n", num_optimizations_,
-               map_->frames_.size(), su.initial_cost, su.final_cost, su.num_iterations, su.termination_type);
+        printf("bundle adjustment %d: %zu frames, cost %.6g -> %.6g, %d iterations, termination %d; map -> arrays %.2f ms, engine %.2f ms, back %.2f ms\n",
+               num_optimizations_, map_->frames_.size(), su.initial_cost, su.final_cost, su.num_iterations, su.termination_type,
+               optimizer_.last_flatten_ms_, optimizer_.last_solve_ms_, optimizer_.last_write_back_ms_);
       }
       // erase the poses that will get optimized
       if (poses_.size() < map_->frames_.size()) poses_.clear();
