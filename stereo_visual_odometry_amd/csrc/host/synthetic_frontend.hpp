@@ -14,6 +14,7 @@
 #include <memory>
 #include <random>
 #include <stdexcept>
+#include <string>
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>
@@ -217,6 +218,7 @@ public:
     estimator_->max_delta_pose_norm_ = max_delta_pose_norm_;
     estimator_->verbose_ = verbose_;
     optimizer_.progress_to_stdout_ = false;
+    optimizer_.dump_directory_ = dump_directory_;
     engine_->get();  // (the engine handle is created here, not inside the first frame's triangulation)
   }
 
@@ -279,6 +281,7 @@ public:
   int bundle_adjustment_window_{20};
   double max_delta_pose_norm_{10.0};
   bool verbose_ = false;
+  std::string dump_directory_;  // when set, every bundle-adjustment window is written there before it is solved
   // what the steps took, wall clock, over the whole run
   double time_triangulate_s_ = 0.0, time_estimate_s_ = 0.0, time_optimize_s_ = 0.0;
   int num_optimizations_ = 0, num_resets_ = 0;

@@ -2,7 +2,7 @@
 // run Frontend::visualOdometryPipeline) over a synthetic sequence, with triangulation, pose estimation and bundle
 // adjustment on the GPU and the image half replaced by a scene of known landmarks (synthetic_frontend.hpp).
 //   vo_pipeline [--frames N] [--kitti-dir <sequence dir> [--poses <file>]] [--no-ba] [--both] [--window 20] [--min-features 500]
-//               [--seed S] [--wrong 0.03] [--lost 0.04] [--verbose]
+//               [--seed S] [--wrong 0.03] [--lost 0.04] [--verbose] [--dump-dir <dir>]
 // Without --kitti-dir the camera drives a gentle S-curve at 0.8 m per frame; with it, the trajectory is the
 // sequence's ground truth (--poses, default <sequence dir>/poses.txt) and the cameras its calib.txt.  Prints the absolute trajectory error against
 // the truth (trajectoryError, kitti.hpp) and what the three GPU steps took.
@@ -20,6 +20,7 @@ using namespace VO;
 struct Result { double rmse, mean, wall_s, tri_ms, est_ms, ba_ms; int windows, resets; std::size_t poses; double mean_features; };
 
 static bool g_verbose = false;
+static std::string g_dump_dir;
 static Result run(const std::vector<SE3d>& truth, const Camera& left, const Camera& right, bool do_ba, int window,
                   unsigned long min_features, unsigned seed, const SyntheticScene::Options& so) {
   auto scene = std::make_shared<SyntheticScene>(truth, left, right, seed, so);
@@ -29,6 +30,7 @@ static Result run(const std::vector<SE3d>& truth, const Camera& left, const Came
   frontend.bundle_adjustment_window_ = window;
   frontend.min_num_features_ = min_features;
   frontend.verbose_ = g_verbose;
+  frontend.dump_directory_ = g_dump_dir;
   frontend.initialize();
   std::vector<std::shared_ptr<Frame>> all;
   double features = 0.0;
@@ -76,6 +78,7 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--poses") && i + 1 < argc) poses_file = argv[++i];
     else if (!strcmp(argv[i], "--no-ba")) do_ba = false;
     else if (!strcmp(argv[i], "--verbose")) g_verbose = true;
+    else if (!strcmp(argv[i], "--dump-dir") && i + 1 < argc) g_dump_dir = argv[++i];
     else if (!strcmp(argv[i], "--both")) both = true;
     else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
   }
