@@ -35,16 +35,40 @@ struct FlatWindow {
 template <class MapT, class KT>
 void flattenMap(const std::shared_ptr<MapT>& map, const KT& K, int camera_model, bool first_frame_constant,
                 FlatWindow* w) {
-  std::unordered_map<const void*, int32_t> index;
+  // landmark storage -> index: an open-addressing table over the pointers (a window makes tens of thousands of
+  // lookups for a few thousand landmarks; std::unordered_map spent a millisecond on them, a third of the call)
+  size_t n_features = 0;
+  for (const auto& frame : map->frames_) n_features += frame->features_left_.size();
+  size_t cap = 64;
+  while (cap < 2 * (map->landmarks_.size() + n_features / 4 + 1)) cap <<= 1;
+  std::vector<const void*> keys(cap, nullptr);
+  std::vector<int32_t> vals(cap, 0);
+  size_t used = 0;
+  auto slot_of = [&](const void* key) {
+    size_t h = (size_t)(((uintptr_t)key >> 4) * 0x9E3779B97F4A7C15ull) & (cap - 1);
+    while (keys[h] && keys[h] != key) h = (h + 1) & (cap - 1);
+    return h;
+  };
   auto landmark_index = [&](double* storage) {
-    auto it = index.find(storage);
-    if (it != index.end()) return it->second;
+    size_t h = slot_of(storage);
+    if (keys[h]) return vals[h];
+    if (2 * (used + 1) > cap) {  // (more landmarks than the map lists: grow and re-enter)
+      std::vector<const void*> old_keys;
+      std::vector<int32_t> old_vals;
+      old_keys.swap(keys); old_vals.swap(vals);
+      cap <<= 1;
+      keys.assign(cap, nullptr); vals.assign(cap, 0);
+      for (size_t i = 0; i < old_keys.size(); ++i)
+        if (old_keys[i]) { const size_t g = slot_of(old_keys[i]); keys[g] = old_keys[i]; vals[g] = old_vals[i]; }
+      h = slot_of(storage);
+    }
     const int32_t id = (int32_t)w->point_storage.size();
-    index.emplace(storage, id);
+    keys[h] = storage; vals[h] = id; ++used;
     w->point_storage.push_back(storage);
     w->point_const.push_back(0);
     return id;
   };
+  w->obs_pose.reserve(n_features); w->obs_point.reserve(n_features); w->uv.reserve(2 * n_features);
   int32_t fi = 0;
   for (const auto& frame : map->frames_) {
     w->pose_storage.push_back(frame->pose_.data());
