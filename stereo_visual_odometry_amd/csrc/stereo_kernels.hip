@@ -231,35 +231,46 @@ __global__ __launch_bounds__(64) void k_pnp_hypotheses(CameraK K, long long n, c
       }
     }
     // Cholesky of the 6x6 normal matrix (upper triangle packed row by row), a whisker of damping against a
-    // degenerate sample; a sample it cannot factor keeps the pose it has
+    // degenerate sample; a sample it cannot factor keeps the pose it has.  (Every loop has constant bounds and is
+    // unrolled: with a data-dependent exit the matrix lived in scratch memory and the fit took three times as long.)
     double L[6][6];
     bool ok = true;
     {
       int q = 0;
+#pragma unroll
       for (int i = 0; i < 6; ++i)
+#pragma unroll
         for (int j = i; j < 6; ++j) { L[j][i] = H[q] + (i == j ? 1e-9 * (1.0 + H[q]) : 0.0); ++q; }
     }
-    for (int j = 0; j < 6 && ok; ++j) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
       double d = L[j][j];
+#pragma unroll
       for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
-      if (!(d > 0.0) || !isfinite(d)) { ok = false; break; }
+      ok = ok && d > 0.0 && isfinite(d);
       d = sqrt(d);
       L[j][j] = d;
+#pragma unroll
       for (int i = j + 1; i < 6; ++i) {
         double v = L[i][j];
+#pragma unroll
         for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k];
         L[i][j] = v / d;
       }
     }
     if (!ok) break;
     double y[6], dlt[6];
+#pragma unroll
     for (int i = 0; i < 6; ++i) {
       double v = -g[i];
+#pragma unroll
       for (int k = 0; k < i; ++k) v -= L[i][k] * y[k];
       y[i] = v / L[i][i];
     }
+#pragma unroll
     for (int i = 5; i >= 0; --i) {
       double v = y[i];
+#pragma unroll
       for (int k = i + 1; k < 6; ++k) v -= L[k][i] * dlt[k];
       dlt[i] = v / L[i][i];
     }
