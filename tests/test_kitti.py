@@ -215,7 +215,8 @@ def test_windows_the_pipeline_hands_to_bundle_adjustment_match_the_oracle(tmp_pa
         # (the windows differ from run to run -- the consensus in front of them amplifies last-bit differences -- so a
         # stopping test decided by the last digits of a cost may fall either way once in a while)
         assert abs(len(s["iterations"]) - len(oits)) <= 1
-        assert abs(s["final_cost"] - so["final_cost"]) <= 1e-6 * so["final_cost"]
-        assert np.abs(g.poses - o.poses).max() <= 1e-6
+        same = len(s["iterations"]) == len(oits)   # (one more step at convergence moves the cost by < 1e-6 of itself)
+        assert abs(s["final_cost"] - so["final_cost"]) <= (1e-6 if same else 3e-6) * so["final_cost"]
+        assert np.abs(g.poses - o.poses).max() <= (1e-6 if same else 1e-4)
         dq = np.abs(g.points - o.points).max(axis=1)
-        assert np.median(dq) <= 1e-6 and np.percentile(dq, 99) <= 1e-4 and dq.max() <= 0.5
+        assert np.median(dq) <= (1e-6 if same else 1e-4) and np.percentile(dq, 99) <= (1e-4 if same else 1e-2) and dq.max() <= 0.5
