@@ -154,8 +154,8 @@ hipError_t launch_se3_plus(long long n, const double* d_poses, const double* d_d
 // One lane per hypothesis: four matches drawn with a counter-based generator (the same draw for the same seed and
 // hypothesis number wherever it runs); the pose of the first three in closed form (p3p.hpp), the fourth choosing among
 // its up to four solutions -- or, when the caller has a prior (consecutive frames of a sequence: the previous frame's
-// pose), that prior --; Gauss-Newton on the four matches' reprojection error from there; then the number of matches
-// the pose reprojects within the threshold.  A second launch walks the hypotheses in the order of their numbers the
+// pose), that prior --; Gauss-Newton on the four matches' reprojection error from there.  A second launch counts the
+// matches every pose reprojects within the threshold.  A third walks the hypotheses in the order of their numbers the
 // way OpenCV's sequential loop does (a better one shrinks the number of iterations still to run by the confidence
 // bound, hypotheses past the bound do not count), takes the best (the lowest number among equals) and marks its
 // inliers.  Every hypothesis is evaluated, all at once; the bound only decides which of them the answer may come from.
@@ -172,7 +172,7 @@ constexpr int kPnpGaussNewton = 10;
 
 __global__ __launch_bounds__(64) void k_pnp_hypotheses(CameraK K, long long n, const double* __restrict__ pts,
                                                        const double* __restrict__ uv, const double* __restrict__ prior,
-                                                       int closed_form, int n_hyp, unsigned long long seed, double thr2,
+                                                       int closed_form, int n_hyp, unsigned long long seed,
                                                        int* __restrict__ count, double* __restrict__ poses) {
   const int h = blockIdx.x * blockDim.x + threadIdx.x;
   if (h >= n_hyp) return;
@@ -379,7 +379,7 @@ hipError_t launch_pnp_ransac(const CameraK& K, long long n, const double* d_pts,
                              hipStream_t s) {
   const double thr2 = reprojection_error * reprojection_error;
   hipLaunchKernelGGL(k_pnp_hypotheses, dim3((unsigned)((n_hyp + 63) / 64)), dim3(64), 0, s, K, n, d_pts, d_uv, d_prior,
-                     closed_form, n_hyp, seed, thr2, d_count, d_poses);
+                     closed_form, n_hyp, seed, d_count, d_poses);
   hipLaunchKernelGGL(k_pnp_count, dim3((unsigned)n_hyp), dim3(256), 0, s, K, n, d_pts, d_uv, (const double*)d_poses, thr2, d_count);
   hipLaunchKernelGGL(k_pnp_select, dim3(1), dim3(256), 0, s, K, n, d_pts, d_uv, n_hyp, (const int*)d_count,
                      (const double*)d_poses, thr2, confidence, d_out, d_mask);
